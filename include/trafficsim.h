@@ -1,0 +1,275 @@
+/*
+ * trafficsim.h - C-ABI of the MI355X-native per-timestep agent-update engine.
+ *
+ * This is the drop-in boundary for the hot path of kurisu-n/TrafficSimulation
+ * (SURVEY.md §8(b)): everything at or below `CityModel.step()`.  The reference has no
+ * C-ABI of its own (it is pure Python + one unused pybind11 file), so every entry point
+ * cites the reference *Python* interface it replaces (paths relative to
+ * /root/reference/Simulation).  The reference-side binding (ctypes) is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch/numpy types.
+ *   - maps are C-contiguous (H, W), indexed [y*W + x], exactly like the reference's numpy
+ *     maps (city_model.py:109-115).  Coordinates are (x, y) pairs like the reference's tuples.
+ *   - every call returns 0 on success or a negative TS_E_* code; `ts_last_error` gives the
+ *     text.  (The reference raises Python exceptions; the facade re-raises from the code.)
+ *   - the caller owns every buffer it passes in; the engine copies in/out and owns all
+ *     device memory.  No pointer returned by the engine outlives the handle.
+ *   - one caller thread per handle (the reference serialises model.step() with the UI on the
+ *     Tornado IOLoop, SURVEY.md §8(b) "Threading").
+ *
+ * The same function set is implemented twice:
+ *   ts_*   libtrafficsim_hip.so   hand-written HIP kernels for gfx950 (the product)
+ *   tso_*  oracle/libtso.so       single-threaded CPU restatement (test infrastructure only)
+ */
+#ifndef TRAFFICSIM_H
+#define TRAFFICSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ts_engine* ts_handle;
+
+enum {
+  TS_OK = 0,
+  TS_E_INVALID = -1,     /* bad argument (shape, range, null) */
+  TS_E_STATE = -2,       /* call order (e.g. step before seeding)  */
+  TS_E_DEVICE = -3,      /* HIP runtime error / no gfx950 device */
+  TS_E_UNSUPPORTED = -4, /* a Defaults combination the engine does not implement */
+  TS_E_CAPACITY = -5     /* a fixed-size device pool overflowed */
+};
+
+/* Defaults.TRAFFIC_LIGHT_AGENT_ALGORITHM (config.py:341-347); RL variants are out of scope. */
+enum {
+  TS_LIGHTS_DISABLED = 0,
+  TS_LIGHTS_FIXED_TIME = 1,
+  TS_LIGHTS_QUEUE_ACTUATED = 2,
+  TS_LIGHTS_PRESSURE_CONTROL = 3,
+  TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL = 4,
+  TS_LIGHTS_NEIGHBOR_GREEN_WAVE = 5
+};
+
+/* The subset of config.py `Defaults` that the hot path reads.  Field names follow the
+ * reference's attribute names (lower-cased).  Filled by ts_default_params() with the values
+ * of config.py. */
+typedef struct TsParams {
+  /* vehicles (config.py:275-326) */
+  int32_t vehicle_min_speed;                         /* VEHICLE_MIN_SPEED = 1 */
+  int32_t vehicle_max_speed;                         /* VEHICLE_MAX_SPEED = 5 */
+  int32_t vehicle_awareness_range;                   /* VEHICLE_AWARENESS_RANGE = 10 */
+  int32_t rain_enabled;                              /* RAIN_ENABLED */
+  int32_t rain_speed_reduction;                      /* RAIN_SPEED_REDUCTION = 2 */
+  int32_t pathfinding_cooldown;                      /* PATHFINDING_COOLDOWN = 5 */
+  int32_t pathfinding_cache;                         /* PATHFINDING_CACHE = True */
+  int32_t stuck_recompute_threshold;                 /* VEHICLE_STUCK_RECOMPUTE_THRESHOLD = 30 */
+  int32_t stuck_recompute_threshold_intersection;    /* ..._INTERSECTION = 1 */
+  int32_t contraflow_overtake_active;                /* VEHICLE_CONTRAFLOW_OVERTAKE_ACTIVE */
+  int32_t max_contraflow_overtake_steps;             /* VEHICLE_MAX_CONTRAFLOW_OVERTAKE_STEPS = 6 */
+  int32_t contraflow_overtake_duration;              /* VEHICLE_CONTRAFLOW_OVERTAKE_DURATION = 30 */
+  int32_t stuck_contraflow_enabled;                  /* VEHICLE_STUCK_CONTRAFLOW_ENABLED */
+  int32_t stuck_contraflow_threshold;                /* = 60 */
+  int32_t stuck_contraflow_threshold_intersection;   /* = 10 */
+  int32_t max_contraflow_stuck_detour_steps;         /* = 20 */
+  int32_t contraflow_stuck_detour_duration;          /* = 10 */
+  int32_t malfunction_active;                        /* VEHICLE_MALFUNCTION_ACTIVE */
+  int32_t malfunction_duration;                      /* = 400 */
+  int32_t sideswipe_active;                          /* VEHICLE_SIDESWIPE_COLLISION_ACTIVE */
+  int32_t sideswipe_duration;                        /* = 600 */
+  double malfunction_chance;                         /* = 1e-7 */
+  double sideswipe_chance;                           /* = 1e-9 */
+  /* A* penalties, captured at import time by astar_numba.py:11-24 */
+  int32_t contraflow_penalty;                        /* VEHICLE_CONTRAFLOW_PENALTY = 5000 */
+  int32_t obstacle_penalty_vehicle;                  /* = 1000 */
+  int32_t obstacle_penalty_stop;                     /* = 500 */
+  int32_t road_type_penalties_enabled;               /* True */
+  int32_t turn_penalty_enabled;                      /* True */
+  int32_t turn_penalty;                              /* = 10 */
+  int32_t dynamic_penalties_enabled;                 /* True */
+  int32_t _pad0;
+  double road_type_penalty_r1;                       /* 0.5 */
+  double road_type_penalty_r2;                       /* 5 */
+  double road_type_penalty_r3;                       /* 50 */
+  double dynamic_penalty_scale;                      /* 4.0 */
+  /* light groups (config.py:338-362) */
+  int32_t light_algorithm;                           /* TS_LIGHTS_* */
+  int32_t transition_duration_enabled;               /* False */
+  int32_t transition_clearance_enabled;              /* True */
+  int32_t all_red_duration;                          /* 2 */
+  int32_t green_duration;                            /* TRAFFIC_LIGHT_GREEN_DURATION = 20 */
+  int32_t qa_min_green;                              /* 5 */
+  int32_t qa_max_green;                              /* 30 */
+  int32_t qa_gap;                                    /* 3 */
+  /* model */
+  int32_t enable_traffic;                            /* ENABLE_TRAFFIC (trip statistics) */
+  int32_t time_per_step_seconds;                     /* TIME_PER_STEP_IN_SECONDS = 6 */
+  int32_t eager_density;                             /* 1: recompute density_map every tick like
+                                                        city_model.py:1853; 0: only when a soft A*
+                                                        needs it (results are identical) */
+  int32_t _pad1;
+} TsParams;
+
+/* Static maps produced by world-gen (`_build_simple_maps`, city_model.py:2151-2199). */
+typedef struct TsWorld {
+  int32_t width, height;
+  const uint8_t* allowed_dirs_map; /* bitmask N=1,E=2,S=4,W=8 (city_model.py:2190-2197) */
+  const int8_t* is_road_map;
+  const int8_t* road_type_map;     /* {0,1,2,3} */
+  const int8_t* intersection_map;
+} TsWorld;
+
+/* Light-group topology (`_create_intersection_light_groups`, city_model.py:1587-1650 and
+ * IntersectionLightGroup.initialize_cached_lane_coords / populate_links,
+ * intersection_light_group.py:118-171, 175-279).  Ragged tables as (offsets[n+1], values). */
+typedef struct TsLightTables {
+  int32_t n_groups, n_lights;
+  const int32_t* g_light_off;    /* [G+1] lights of group g = [off[g], off[g+1]) (traffic_lights order) */
+  const int32_t* light_xy;       /* [L*2] light cell */
+  const int32_t* light_ctrl_off; /* [L+1] controlled_blocks of each light */
+  const int32_t* light_ctrl_xy;
+  const int32_t* g_ns_off;       /* opposite_pairs["N-S"]: global light indices */
+  const int32_t* g_ns;
+  const int32_t* g_ew_off;       /* opposite_pairs["W-E"] */
+  const int32_t* g_ew;
+  const int32_t* g_icell_off;    /* intersection_cells */
+  const int32_t* g_icell_xy;
+  const int32_t* g_ns_in_off;    /* ns_in_coords ... ew_out_coords (118-171) */
+  const int32_t* g_ns_in_xy;
+  const int32_t* g_ns_out_off;
+  const int32_t* g_ns_out_xy;
+  const int32_t* g_ew_in_off;
+  const int32_t* g_ew_in_xy;
+  const int32_t* g_ew_out_off;
+  const int32_t* g_ew_out_xy;
+  const int32_t* g_neighbors;    /* [G*4*2] (dir code N0 E1 S2 W3 or -1, group index): neighbor_groups
+                                    after populate_links() has been re-run on the finished model */
+  const int32_t* g_neighbors_ctor; /* same layout, as left by the constructor: populate_links() runs
+                                    before the model assigns cell.intersection_group
+                                    (city_model.py:1639-1650), so opposite_pairs is empty and only
+                                    earlier groups are visible until the group's first
+                                    _execute_phase_change reaches get_opposite_traffic_lights()
+                                    (intersection_light_group.py:303-307, 369), which re-populates.
+                                    NULL = same as g_neighbors. */
+} TsLightTables;
+
+/* Kinds of non-vehicle entries in the Mesa schedule, appended in insertion order
+ * (city_model.py:1642, 1738, 200, 204).  Their presence matters: RandomActivation shuffles
+ * ALL scheduled agents each tick. */
+enum {
+  TS_AGENT_LIGHT_GROUP = 0, /* next IntersectionLightGroup, in table order */
+  TS_AGENT_NOOP = 1,        /* CityBlock / RainManager with rain off: occupies a shuffle slot only */
+  TS_AGENT_CLOCK = 3        /* DynamicTrafficAgent with empty schedule: elapsed += dt (dynamic_traffic_generator.py:153-155) */
+};
+
+/* dynamic_traffic_generator.py:102-131 counters that the hot path writes. */
+typedef struct TsCounters {
+  int64_t stuck, collisions, malfunctions, overtaking, in_stuck_detour, parked;
+  int64_t live_internal, live_through;
+  int64_t count_completed_internal, count_completed_through;
+  int64_t total_distance_internal, total_distance_through;
+  int64_t errored_internal, errored_through;
+  double total_duration_internal, total_duration_through;
+  double elapsed;
+  /* engine statistics (not in the reference) */
+  int64_t step_count;          /* CityModel.step_count */
+  int64_t agent_steps;         /* sum over ticks of vehicles stepped (the benchmark unit) */
+  int64_t astar_calls, astar_expansions, astar_relaxations;
+  int64_t move_rounds;         /* dependency-resolution rounds executed by the move phase */
+  int64_t rng_fixups;          /* decide-phase re-scans caused by malfunction/collision events */
+} TsCounters;
+
+/* One row per live vehicle, in `active_vehicle_agents` order (city_model.py:1903). */
+enum {
+  TS_V_SPAWN_IDX = 0, TS_V_X, TS_V_Y, TS_V_BASE_SPEED, TS_V_CURRENT_SPEED, TS_V_MAX_STEPS,
+  TS_V_DIRECTION,      /* N0 E1 S2 W3, -1 = None */
+  TS_V_STUCK_TICKS, TS_V_COOLDOWN, TS_V_FLAGS, TS_V_STRANDED_LEFT, TS_V_STEPS_TRAVELED,
+  TS_V_PATH_LEN, TS_V_PATH_CRC, /* crc32 of the remaining path as int32 (x,y) pairs, 0 if empty */
+  TS_V_OVERTAKE_DUR, TS_V_DETOUR_DUR,
+  TS_V_NFIELDS
+};
+enum {
+  TS_F_EARLY_EXIT = 1, TS_F_STUCK = 2, TS_F_PARKED = 4, TS_F_COLLISION = 8, TS_F_MALFUNCTION = 16,
+  TS_F_OVERTAKING = 32, TS_F_DETOUR = 64, TS_F_BLOCKED = 128,
+  TS_F_HAS_PREV = 256 /* previous_pos == pos (vehicle_base.py:688) */
+};
+/* One row per light group. */
+enum {
+  TS_G_CURRENT_PHASE = 0, TS_G_PENDING_PHASE, /* -1 = None */
+  TS_G_QUEUE_TIMER, TS_G_GAP_TIMER, TS_G_LAST_ARRIVAL, TS_G_FIXED_TIME_TIMER, TS_G_FT_PHASE,
+  TS_G_NS_PRESSURE, TS_G_EW_PRESSURE,
+  TS_G_NFIELDS
+};
+enum { TS_MAP_OCCUPANCY = 0, TS_MAP_STOP = 1, TS_MAP_STUCK = 2, TS_MAP_RAIN = 3 };
+enum { TS_RNG_GLOBAL = 0, TS_RNG_SCHEDULER = 1 };
+enum { TS_POP_UNDEFINED = 0, TS_POP_INTERNAL = 1, TS_POP_THROUGH = 2 };
+
+/* config.py defaults. */
+void ts_default_params(TsParams* p);
+
+/* CityModel.__init__ after world-gen (city_model.py:109-115, 147-148): allocate the dynamic
+ * maps and take a copy of the static ones. */
+int ts_create(const TsWorld* world, const TsParams* params, ts_handle* out);
+int ts_destroy(ts_handle h);
+const char* ts_last_error(ts_handle h);
+
+/* IntersectionLightGroup construction (city_model.py:1639-1650): registers the groups.  With
+ * an algorithm other than DISABLED every group starts with pending_phase = 0
+ * (intersection_light_group.py:115-116).  Does NOT add them to the schedule. */
+int ts_set_lights(ts_handle h, const TsLightTables* t);
+
+/* schedule.add() for non-vehicle agents, in insertion order (city_model.py:1642, 1738, 200, 204). */
+int ts_schedule_add(ts_handle h, int32_t kind, int32_t count);
+
+/* random.setstate() for the two MT19937 streams: TS_RNG_GLOBAL = module-level `random`
+ * (vehicle_base.py:112, 600, 609), TS_RNG_SCHEDULER = model.random (city_model.py:55, 1858).
+ * `mt` is random.getstate()[1][:624], `index` is [624]. */
+int ts_seed(ts_handle h, int32_t stream, const uint32_t* mt, uint32_t index);
+/* random.seed(int) / random.Random(int) for a non-negative integer seed. */
+int ts_seed_int(ts_handle h, int32_t stream, uint64_t seed);
+int ts_rng_state(ts_handle h, int32_t stream, uint32_t* mt_out, uint32_t* index_out);
+
+/* VehicleAgent(custom_id, model, start_cell, target_cell, population_type) for n vehicles, in
+ * order (vehicle_base.py:29-89 -> city_model.place_vehicle 1897-1918 -> _compute_path 143-167).
+ * path_off == NULL: the initial path is computed as the reference does (cache, then the
+ * phase 1-4 planner) on the maps as they are at that moment.  Otherwise vehicle i's initial
+ * path is path_xy[2*path_off[i] .. 2*path_off[i+1]) (4-adjacent chain starting next to the
+ * start cell).  The density map must exist first in the reference; here it is
+ * produced on demand. */
+int ts_add_vehicles(ts_handle h, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
+                    const int32_t* population_type, const int32_t* path_off, const int32_t* path_xy);
+
+/* Host writes between ticks (UI handlers / RainManager): whole-map upload of stop_map or
+ * rain_map (cell.py:241-251, rain.py:156-184). */
+int ts_upload_map(ts_handle h, int32_t which, const int8_t* src);
+
+/* CityModel.step() x n_ticks (city_model.py:1831-1860). */
+int ts_step(ts_handle h, int32_t n_ticks);
+
+int ts_num_vehicles(ts_handle h);  /* len(active_vehicle_agents) */
+int ts_num_groups(ts_handle h);
+int ts_num_scheduled(ts_handle h); /* len(schedule._agents) */
+int ts_download_map(ts_handle h, int32_t which, int8_t* dst);
+int ts_download_density(ts_handle h, float* dst); /* _update_density_map (1764-1778), recomputed now */
+int ts_download_vehicles(ts_handle h, int32_t* rows, int32_t cap_rows); /* [n][TS_V_NFIELDS] */
+/* remaining path of the vehicle at position `active_pos`; returns its length (cells). */
+int ts_download_path(ts_handle h, int32_t active_pos, int32_t* xy, int32_t cap_cells);
+int ts_download_groups(ts_handle h, int32_t* rows); /* [G][TS_G_NFIELDS] */
+int ts_counters(ts_handle h, TsCounters* out);
+
+/* The pathfinder operator seam: astar(width, height, sx, sy, gx, gy, occupancy_map, stop_map,
+ * is_road_map, road_type_map, allowed_dirs_map, respect_awareness=False, awareness_range,
+ * density_map, soft_obstacles, ignore_flow, maximum_steps) -> [(x, y)]  (astar_numba.py:243-281),
+ * evaluated on the engine's current maps.  Returns the path length (0 = no path) or <0. */
+int ts_astar(ts_handle h, int32_t sx, int32_t sy, int32_t gx, int32_t gy, int32_t soft_obstacles,
+             int32_t ignore_flow, int32_t maximum_steps, int32_t* out_xy, int32_t cap_cells);
+
+/* Test hook: overwrite occupancy_map without placing vehicles (A* / density known-answer tests). */
+int ts_debug_set_occupancy(ts_handle h, const int8_t* src);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAFFICSIM_H */

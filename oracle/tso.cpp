@@ -1,0 +1,1274 @@
+/*
+ * tso.cpp - CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A single-threaded C++ restatement of the reference's sequential per-tick semantics
+ * (SURVEY.md §8(a) A1-A16), exporting the same C-ABI as include/trafficsim.h under the
+ * prefix `tso_`.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product (libtrafficsim_hip.so) never links or calls it.
+ *
+ * Parity pinning: checked against the golden vectors of tests/golden/ (MT19937 streams from
+ * CPython's own `random`; density from the real scipy; A* KATs and per-tick traces from the
+ * reference's own source files executed with stand-ins for the absent mesa/numba/tensorflow
+ * packages - see tests/golden/standins/README.md).  The Mesa scheduler contract (A4) is not
+ * pinned by the reference itself (no lock file): "parity unpinned" at that boundary.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * /root/reference/Simulation).
+ */
+#include "../include/trafficsim.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// MT19937 exactly as CPython's _randommodule.c (random.random / getrandbits / _randbelow / randint /
+// shuffle; Lib/random.py 3.10).  Pinned by tests/golden/mt_kats.npz.
+// ---------------------------------------------------------------------------------------------
+struct MT {
+  uint32_t mt[624];
+  uint32_t idx = 625;
+  void init_genrand(uint32_t s) {
+    mt[0] = s;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253U * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    idx = 624;
+  }
+  void init_by_array(const uint32_t* key, size_t len) {
+    init_genrand(19650218U);
+    size_t i = 1, j = 0;
+    size_t k = (624 > len ? 624 : len);
+    for (; k; k--) {
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525U)) + key[j] + (uint32_t)j;
+      i++; j++;
+      if (i >= 624) { mt[0] = mt[623]; i = 1; }
+      if (j >= len) j = 0;
+    }
+    for (k = 623; k; k--) {
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941U)) - (uint32_t)i;
+      i++;
+      if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    }
+    mt[0] = 0x80000000U;
+  }
+  void seed_int(uint64_t s) {  // random.seed(int): key = 32-bit little-endian chunks of abs(s)
+    uint32_t key[2] = {(uint32_t)(s & 0xffffffffU), (uint32_t)(s >> 32)};
+    init_by_array(key, key[1] ? 2 : 1);
+  }
+  uint32_t next() {
+    if (idx >= 624) {
+      static const uint32_t mag01[2] = {0x0U, 0x9908b0dfU};
+      int kk;
+      uint32_t y;
+      for (kk = 0; kk < 624 - 397; kk++) {
+        y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+        mt[kk] = mt[kk + 397] ^ (y >> 1) ^ mag01[y & 1U];
+      }
+      for (; kk < 623; kk++) {
+        y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+        mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ mag01[y & 1U];
+      }
+      y = (mt[623] & 0x80000000U) | (mt[0] & 0x7fffffffU);
+      mt[623] = mt[396] ^ (y >> 1) ^ mag01[y & 1U];
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680U;
+    y ^= (y << 15) & 0xefc60000U;
+    y ^= (y >> 18);
+    return y;
+  }
+  double random() {
+    uint32_t a = next() >> 5, b = next() >> 6;
+    return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+  }
+  uint32_t getrandbits(int k) { return next() >> (32 - k); }  // 1 <= k <= 32
+  uint32_t randbelow(uint32_t n) {                             // Random._randbelow_with_getrandbits
+    int k = 32 - __builtin_clz(n);                             // n.bit_length(), n >= 1
+    uint32_t r = getrandbits(k);
+    while (r >= n) r = getrandbits(k);
+    return r;
+  }
+  int randint(int a, int b) { return a + (int)randbelow((uint32_t)(b - a + 1)); }
+};
+
+// crc32 (zlib polynomial) of int32 (x,y) pairs - identical to zlib.crc32(np.int32 array bytes)
+uint32_t crc_table[256];
+bool crc_init_done = false;
+void crc_init() {
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320U ^ (c >> 1)) : (c >> 1);
+    crc_table[i] = c;
+  }
+  crc_init_done = true;
+}
+inline uint32_t crc_update(uint32_t crc, const void* buf, size_t len) {
+  const uint8_t* p = (const uint8_t*)buf;
+  for (size_t i = 0; i < len; i++) crc = crc_table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
+  return crc;
+}
+
+// N, E, S, W deltas (astar_numba.py:9; numba_utilities.py:5-10; config.py:64)
+const int DX[4] = {0, 1, 0, -1};
+const int DY[4] = {1, 0, -1, 0};
+const int INF = 0x3F3F3F3F;
+
+struct Vehicle {
+  int spawn_idx;
+  int pos;     // cell index, -1 once removed
+  int target;  // cell index
+  int pop_type;
+  std::vector<int> path;  // remaining path = path[head..]
+  size_t head = 0;
+  int base_speed = 0, current_speed = 0, max_steps = 0;
+  bool blocked_by_vehicle = false;
+  int direction = -1;
+  int cooldown = 0;
+  bool is_overtaking = false;
+  std::vector<int> overtake_path, pre_overtake_path;
+  bool overtake_path_none = false;  // `self.overtake_path = None` (vehicle_base.py:461)
+  int overtaking_duration = -1;
+  bool is_in_stuck_detour = false;
+  std::vector<int> pre_stuck_detour_path, stuck_detour_path;
+  bool stuck_detour_path_none = false;
+  int stuck_detour_duration = -1;
+  int stuck_ticks = 0;
+  bool early_exit = false, is_stuck = false, is_parked = false, is_in_collision = false,
+       is_in_malfunction = false;
+  bool remove_on_arrival = true;
+  bool has_prev = false;  // previous_pos == pos
+  int stranded_left = 0;
+  double depart_time = 0.0;
+  int steps_traveled = 0;
+  bool alive = true;
+  int next_in_cell = -1;  // MultiGrid cell list (vehicles only, arrival order)
+  size_t plen() const { return path.size() - head; }
+  bool stranded() const { return is_in_collision || is_in_malfunction; }
+};
+
+struct Group {
+  std::vector<int> lights;                 // global light indices (traffic_lights order)
+  std::vector<int> ns_lights, ew_lights;   // opposite_pairs
+  std::vector<int> icells, ns_in, ns_out, ew_in, ew_out;  // cell indices
+  int nb_dir[4], nb_grp[4];            // neighbor_groups once re-populated
+  int nb_dir_ctor[4], nb_grp_ctor[4];  // neighbor_groups as left by the constructor
+  bool links_repopulated = false;      // get_opposite_traffic_lights() re-ran populate_links()
+  int current_phase = -1, pending_phase = -1;
+  int transition_timer = 0, clearance_timer = 0;
+  int ft_phase = 0, fixed_time_timer = 0;
+  int queue_timer = 0, gap_timer = 0, last_arrival = 0;
+  int ns_pressure = 0, ew_pressure = 0;
+};
+
+struct SchedEntry {
+  int kind;  // TS_AGENT_* or 100 = vehicle
+  int ref;
+  bool alive;
+};
+
+}  // namespace
+
+struct ts_engine {
+  int W = 0, H = 0, N = 0;
+  TsParams P;
+  std::vector<uint8_t> allowed;
+  std::vector<int8_t> is_road, road_type, intersection, occ, stop, stuck, rain;
+  std::vector<float> density;
+  std::vector<int8_t> occ_snap;  // occupancy at the last _update_density_map() call site
+  bool density_valid = false;
+  std::vector<int> cell_head;  // first vehicle in cell (MultiGrid list minus the CellAgent)
+  std::vector<Vehicle> veh;
+  std::vector<int> active;     // active_vehicle_agents (vehicle ids; -1 = removed, compacted per tick)
+  std::vector<SchedEntry> sched;
+  std::vector<int> veh_sched;  // vehicle id -> schedule entry
+  std::vector<Group> groups;
+  std::vector<int> light_cell;
+  std::vector<std::vector<int>> light_ctrl;
+  int groups_scheduled = 0;
+  MT rng_global, rng_sched;
+  bool seeded[2] = {false, false};
+  TsCounters C;
+  std::unordered_map<uint64_t, std::vector<int>> path_cache;  // city._path_cache
+  std::string err;
+  // A* scratch (epoch-stamped so the O(N) init of astar_numba.py:119-122 is not repeated)
+  std::vector<int> a_dist, a_came, a_epoch;
+  int epoch = 0;
+  std::vector<int> hf, hg, hs, hi;
+  std::vector<int8_t> hdir;
+};
+
+namespace {
+
+typedef ts_engine E;
+
+int fail(E* e, int code, const std::string& msg) {
+  if (e) e->err = msg;
+  return code;
+}
+
+// --------------------------- MultiGrid cell lists (vehicles only) ----------------------------
+void cell_append(E* e, int cell, int vid) {
+  e->veh[vid].next_in_cell = -1;
+  int h = e->cell_head[cell];
+  if (h < 0) { e->cell_head[cell] = vid; return; }
+  while (e->veh[h].next_in_cell >= 0) h = e->veh[h].next_in_cell;
+  e->veh[h].next_in_cell = vid;
+}
+void cell_remove(E* e, int cell, int vid) {
+  int h = e->cell_head[cell];
+  if (h == vid) { e->cell_head[cell] = e->veh[vid].next_in_cell; return; }
+  while (h >= 0 && e->veh[h].next_in_cell != vid) h = e->veh[h].next_in_cell;
+  if (h >= 0) e->veh[h].next_in_cell = e->veh[vid].next_in_cell;
+}
+
+// ------------------------------ density (city_model.py:1764-1778) -----------------------------
+// Exact recipe of scipy.ndimage.uniform_filter on float32 input (two uniform_filter1d passes with
+// double accumulators and a float32 intermediate), `* 441` in float32, float32 division.
+void box_sum_f32(const int8_t* src, int W, int H, int r, std::vector<float>& out) {
+  const int size = 2 * r + 1;
+  std::vector<float> t((size_t)W * H);
+  // axis 0 (y): running window count (exact), /size in double, store float32
+  for (int x = 0; x < W; x++) {
+    for (int y = 0; y < H; y++) {
+      int c = 0;
+      int y0 = std::max(0, y - r), y1 = std::min(H - 1, y + r);
+      for (int yy = y0; yy <= y1; yy++) c += src[(size_t)yy * W + x];
+      t[(size_t)y * W + x] = (float)((double)c / (double)size);
+    }
+  }
+  out.assign((size_t)W * H, 0.f);
+  for (int y = 0; y < H; y++) {
+    for (int x = 0; x < W; x++) {
+      double s = 0.0;
+      int x0 = std::max(0, x - r), x1 = std::min(W - 1, x + r);
+      for (int xx = x0; xx <= x1; xx++) s += (double)t[(size_t)y * W + xx];
+      float v = (float)(s / (double)size);
+      out[(size_t)y * W + x] = v * (float)(size * size);
+    }
+  }
+}
+void update_density(E* e) {
+  const int r = e->P.vehicle_awareness_range;
+  std::vector<float> so, sr;
+  box_sum_f32(e->occ_snap.data(), e->W, e->H, r, so);
+  box_sum_f32(e->is_road.data(), e->W, e->H, r, sr);
+  e->density.resize(e->N);
+  for (int i = 0; i < e->N; i++) e->density[i] = sr[i] > 0.f ? so[i] / sr[i] : 0.f;
+  e->density_valid = true;
+}
+// faster sliding-window variant used by the per-tick eager path (bitwise identical: window counts
+// are exact integers; the axis-1 double sums of <= 21 float32 values are exact in any order)
+void update_density_fast(E* e) {
+  const int r = e->P.vehicle_awareness_range, W = e->W, H = e->H, size = 2 * r + 1;
+  std::vector<float> t0((size_t)W * H), t1((size_t)W * H);
+  const int8_t* srcs[2] = {e->occ_snap.data(), e->is_road.data()};
+  std::vector<float>* ts[2] = {&t0, &t1};
+  for (int m = 0; m < 2; m++) {
+    const int8_t* src = srcs[m];
+    std::vector<float>& t = *ts[m];
+    std::vector<int> col(W, 0);
+    for (int yy = 0; yy <= std::min(H - 1, r); yy++)
+      for (int x = 0; x < W; x++) col[x] += src[(size_t)yy * W + x];
+    for (int y = 0; y < H; y++) {
+      for (int x = 0; x < W; x++) t[(size_t)y * W + x] = (float)((double)col[x] / (double)size);
+      int add = y + r + 1, sub = y - r;
+      if (add < H) for (int x = 0; x < W; x++) col[x] += src[(size_t)add * W + x];
+      if (sub >= 0) for (int x = 0; x < W; x++) col[x] -= src[(size_t)sub * W + x];
+    }
+  }
+  e->density.resize(e->N);
+  for (int y = 0; y < H; y++) {
+    const float* a = &t0[(size_t)y * W];
+    const float* b = &t1[(size_t)y * W];
+    // running double sums: every partial sum is an exact multiple of 2^-29 below 2^5, so adds and
+    // subtracts are exact and the result equals scipy's per-line running sum bit for bit
+    double s0 = 0.0, s1 = 0.0;
+    for (int xx = 0; xx <= std::min(W - 1, r); xx++) { s0 += (double)a[xx]; s1 += (double)b[xx]; }
+    for (int x = 0; x < W; x++) {
+      float v0 = (float)(s0 / (double)size) * (float)(size * size);
+      float v1 = (float)(s1 / (double)size) * (float)(size * size);
+      e->density[(size_t)y * W + x] = v1 > 0.f ? v0 / v1 : 0.f;
+      int add = x + r + 1, sub = x - r;
+      if (add < W) { s0 += (double)a[add]; s1 += (double)b[add]; }
+      if (sub >= 0) { s0 -= (double)a[sub]; s1 -= (double)b[sub]; }
+    }
+  }
+  e->density_valid = true;
+}
+
+// ------------------------------ A* (astar_numba.py:87-239) ------------------------------------
+// Verbatim semantics incl. both quirks of SURVEY §8(a) A13: (1) dir_arr is indexed by heap SLOT and
+// is not swapped by the sift routines; (2) `ng` is a float (R1 penalty 0.5) and truncates on store.
+// respect_awareness (FOV) is off by default (config.py:278) and not restated.
+inline void heap_sift_up(E* e, int i) {
+  while (i > 0) {
+    int parent = (i - 1) / 2;
+    if (e->hf[i] < e->hf[parent]) {
+      std::swap(e->hf[i], e->hf[parent]);
+      std::swap(e->hg[i], e->hg[parent]);
+      std::swap(e->hs[i], e->hs[parent]);
+      std::swap(e->hi[i], e->hi[parent]);
+      i = parent;
+    } else break;
+  }
+}
+inline void heap_sift_down(E* e, int size) {
+  int idx = 0;
+  for (;;) {
+    int left = 2 * idx + 1, right = left + 1, smallest = idx;
+    if (left < size && e->hf[left] < e->hf[smallest]) smallest = left;
+    if (right < size && e->hf[right] < e->hf[smallest]) smallest = right;
+    if (smallest != idx) {
+      std::swap(e->hf[idx], e->hf[smallest]);
+      std::swap(e->hg[idx], e->hg[smallest]);
+      std::swap(e->hs[idx], e->hs[smallest]);
+      std::swap(e->hi[idx], e->hi[smallest]);
+      idx = smallest;
+    } else break;
+  }
+}
+inline void heap_reserve(E* e, int n) {
+  if ((int)e->hf.size() < n) {
+    size_t m = std::max<size_t>(n, e->hf.size() * 2 + 64);
+    e->hf.resize(m); e->hg.resize(m); e->hs.resize(m); e->hi.resize(m); e->hdir.resize(m);
+  }
+}
+
+void astar(E* e, int sx, int sy, int gx, int gy, bool soft, bool ignore_flow, int maximum_steps,
+           std::vector<int>& out) {
+  out.clear();
+  e->C.astar_calls++;
+  const int W = e->W, H = e->H;
+  const TsParams& P = e->P;
+  if ((int)e->a_dist.size() != e->N) {
+    e->a_dist.assign(e->N, INF); e->a_came.assign(e->N, -1); e->a_epoch.assign(e->N, 0); e->epoch = 0;
+  }
+  if (soft && !e->density_valid) update_density_fast(e);
+  const int ep = ++e->epoch;
+  auto dist_get = [&](int i) { return e->a_epoch[i] == ep ? e->a_dist[i] : INF; };
+  auto dist_set = [&](int i, int d, int from) { e->a_epoch[i] = ep; e->a_dist[i] = d; e->a_came[i] = from; };
+  const int start_idx = sy * W + sx, goal_idx = gy * W + gx;
+  dist_set(start_idx, 0, -1);
+  heap_reserve(e, 8);
+  int heap_size = 1;
+  e->hf[0] = std::abs(sx - gx) + std::abs(sy - gy);
+  e->hg[0] = 0; e->hs[0] = 0; e->hi[0] = start_idx; e->hdir[0] = -1;
+  while (heap_size > 0) {
+    int g = e->hg[0], steps = e->hs[0], cur = e->hi[0];
+    int prev_dir = e->hdir[0];
+    heap_size--;
+    if (heap_size > 0) {
+      e->hf[0] = e->hf[heap_size]; e->hg[0] = e->hg[heap_size]; e->hs[0] = e->hs[heap_size];
+      e->hi[0] = e->hi[heap_size]; e->hdir[0] = e->hdir[heap_size];
+      heap_sift_down(e, heap_size);
+    }
+    if (cur == goal_idx) {
+      int idx = cur;
+      while (idx != start_idx) { out.push_back(idx); idx = e->a_came[idx]; }
+      std::reverse(out.begin(), out.end());
+      return;
+    }
+    if (g > dist_get(cur)) continue;
+    e->C.astar_expansions++;
+    const int cx = cur % W, cy = cur / W;
+    for (int d = 0; d < 4; d++) {
+      int nx = cx + DX[d], ny = cy + DY[d];
+      if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
+      int ns = steps + 1;
+      if (ns > maximum_steps) continue;
+      int nidx = ny * W + nx;
+      double ng = g + 1;
+      if (P.turn_penalty_enabled && prev_dir != -1 && d != prev_dir) ng += P.turn_penalty;
+      uint8_t bits = e->allowed[cur];
+      if ((bits & (1 << d)) == 0) {
+        if (ignore_flow && e->is_road[nidx] == 1) ng += P.contraflow_penalty;
+        else continue;
+      }
+      if (e->occ[nidx] == 1) {
+        if (soft && P.dynamic_penalties_enabled) {
+          double p = P.obstacle_penalty_vehicle;
+          double local_density = (double)e->density[nidx];
+          ng += (double)(long long)(p * (1.0 + P.dynamic_penalty_scale * local_density));
+        } else if (soft) ng += P.obstacle_penalty_vehicle;
+        else continue;
+      }
+      if (e->stop[nidx] == 1) {
+        if (soft) ng += P.obstacle_penalty_stop;
+        else continue;
+      }
+      if (P.road_type_penalties_enabled && e->is_road[nidx] == 1) {
+        int rt = e->road_type[nidx];
+        if (rt == 1) ng += P.road_type_penalty_r1;
+        else if (rt == 2) ng += P.road_type_penalty_r2;
+        else if (rt == 3) ng += P.road_type_penalty_r3;
+      }
+      if (ng < (double)dist_get(nidx)) {
+        e->C.astar_relaxations++;
+        dist_set(nidx, (int)ng, cur);
+        int h = std::abs(nx - gx) + std::abs(ny - gy);
+        int i = heap_size;
+        heap_reserve(e, i + 1);
+        e->hf[i] = (int)(ng + h); e->hg[i] = (int)ng; e->hs[i] = ns; e->hi[i] = nidx; e->hdir[i] = (int8_t)d;
+        heap_sift_up(e, i);
+        heap_size++;
+      }
+    }
+  }
+}
+
+// ------------------------------ vehicle helpers -----------------------------------------------
+inline int first_vehicle_on_cell(E* e, int cell) { return e->cell_head[cell]; }  // _vehicle_on_cell (711-717)
+
+void set_collision(E* e, Vehicle& v, int ticks) {  // vehicle_base.py:534-541
+  v.is_in_collision = true; v.is_in_malfunction = false; v.stranded_left = ticks;
+  v.base_speed = 0; v.current_speed = 0; e->C.collisions++;
+}
+void set_malfunction(E* e, Vehicle& v, int ticks) {  // vehicle_base.py:543-550
+  v.is_in_malfunction = true; v.is_in_collision = false; v.stranded_left = ticks;
+  v.base_speed = 0; v.current_speed = 0; e->C.malfunctions++;
+}
+bool tick_stranded(E* e, Vehicle& v) {  // vehicle_base.py:552-565
+  if (!v.stranded()) return false;
+  v.stranded_left -= 1;
+  if (v.stranded_left <= 0) {
+    if (v.is_in_collision) e->C.collisions--;
+    if (v.is_in_malfunction) e->C.malfunctions--;
+    v.is_in_collision = false; v.is_in_malfunction = false; v.stranded_left = 0;
+  }
+  return v.stranded();
+}
+
+void remove_vehicle(E* e, int vid);
+
+void on_target_reached(E* e, int vid) {  // vehicle_base.py:755-775
+  Vehicle& v = e->veh[vid];
+  if (e->P.enable_traffic) {
+    double duration = e->C.elapsed - v.depart_time;
+    if (v.pop_type == TS_POP_INTERNAL) {
+      e->C.total_duration_internal += duration; e->C.total_distance_internal += v.steps_traveled;
+      e->C.count_completed_internal++;
+    } else if (v.pop_type == TS_POP_THROUGH) {
+      e->C.total_duration_through += duration; e->C.total_distance_through += v.steps_traveled;
+      e->C.count_completed_through++;
+    }
+  }
+  if (v.remove_on_arrival) remove_vehicle(e, vid);
+  else if (!v.is_parked) { v.is_parked = true; e->C.parked++; }
+}
+
+void remove_vehicle(E* e, int vid) {  // city_model.py:1920-1941
+  Vehicle& v = e->veh[vid];
+  e->occ[v.pos] = 0; e->stuck[v.pos] = 0;
+  for (size_t i = 0; i < e->active.size(); i++) if (e->active[i] == vid) { e->active[i] = -1; break; }
+  cell_remove(e, v.pos, vid);
+  e->sched[e->veh_sched[vid]].alive = false;
+  if (v.pop_type == TS_POP_INTERNAL) e->C.live_internal--;
+  else if (v.pop_type == TS_POP_THROUGH) e->C.live_through--;
+  v.alive = false; v.pos = -1;
+}
+
+// _scan_ahead_for_obstacles (vehicle_base.py:422-452) incl. its index-0-only break
+void scan_ahead(E* e, const Vehicle& v, int& idx_stop, int& idx_vehicle) {
+  idx_stop = -1; idx_vehicle = -1;
+  size_t n = v.plen();
+  if (n == 0) return;
+  int look = (int)std::min<size_t>((size_t)e->P.vehicle_awareness_range, n);
+  for (int i = 0; i < look; i++) {
+    int c = v.path[v.head + i];
+    if (idx_stop < 0 && e->stop[c] == 1) idx_stop = i;
+    if (idx_vehicle < 0 && e->occ[c] == 1) idx_vehicle = i;
+    if (idx_stop == 0 || idx_vehicle == 0) break;
+  }
+}
+
+inline bool contains(const std::vector<int>& p, int cell) {
+  return std::find(p.begin(), p.end(), cell) != p.end();
+}
+
+// _compute_path_internal (vehicle_base.py:199-420)
+void compute_path_internal(E* e, int vid, std::vector<int>& out) {
+  Vehicle& v = e->veh[vid];
+  const TsParams& P = e->P;
+  const int W = e->W;
+  const int sx = v.pos % W, sy = v.pos / W, gx = v.target % W, gy = v.target / W;
+  std::vector<int> bypass;
+  // Phase 0a: re-merge after overtaking (219-247)
+  if (v.is_overtaking && !v.pre_overtake_path.empty()) {
+    int merge_idx = -1;
+    for (size_t i = 0; i < v.pre_overtake_path.size(); i++)
+      if (e->occ[v.pre_overtake_path[i]] == 0) { merge_idx = (int)i; break; }
+    if (merge_idx >= 0) {
+      int b = v.pre_overtake_path[merge_idx];
+      astar(e, sx, sy, b % W, b / W, false, true, P.max_contraflow_overtake_steps, bypass);
+      if (!bypass.empty() && bypass.back() == b) {
+        v.overtake_path = bypass; v.overtake_path_none = false;
+        out = bypass;
+        out.insert(out.end(), v.pre_overtake_path.begin() + merge_idx + 1, v.pre_overtake_path.end());
+        return;
+      }
+    }
+  }
+  // Phase 0b: re-merge after a stuck detour (249-277)
+  if (v.is_in_stuck_detour && !v.pre_stuck_detour_path.empty()) {
+    int merge_idx = -1;
+    for (size_t i = 0; i < v.pre_stuck_detour_path.size(); i++)
+      if (e->occ[v.pre_stuck_detour_path[i]] == 0) { merge_idx = (int)i; break; }
+    if (merge_idx >= 0) {
+      int b = v.pre_stuck_detour_path[merge_idx];
+      astar(e, sx, sy, b % W, b / W, false, true, P.max_contraflow_overtake_steps, bypass);
+      if (!bypass.empty() && bypass.back() == b) {
+        v.stuck_detour_path = bypass; v.stuck_detour_path_none = false;
+        out = bypass;
+        out.insert(out.end(), v.pre_stuck_detour_path.begin() + merge_idx + 1, v.pre_stuck_detour_path.end());
+        return;
+      }
+    }
+  }
+  // Phase 1: strict (280-291); Phase 2: soft obstacles (294-306)
+  std::vector<int> path;
+  astar(e, sx, sy, gx, gy, false, false, 0x7FFFFFFF, path);
+  if (path.empty()) astar(e, sx, sy, gx, gy, true, false, 0x7FFFFFFF, path);
+  // Phase 3: contraflow overtake of a stranded/parked blocker (309-366)
+  if (P.contraflow_overtake_active && !path.empty()) {
+    int aw = P.vehicle_awareness_range;
+    int idx_stop = -1, idx_vehicle = -1;
+    int look = (int)std::min<size_t>((size_t)aw, path.size());
+    for (int i = 0; i < look; i++) {
+      if (idx_stop < 0 && e->stop[path[i]] == 1) idx_stop = i;
+      if (idx_vehicle < 0 && e->occ[path[i]] == 1) idx_vehicle = i;
+      if (idx_stop >= 0 && idx_vehicle >= 0) break;
+    }
+    if (idx_vehicle == 0) {
+      int b = first_vehicle_on_cell(e, path[0]);
+      if (b >= 0 && (e->veh[b].stranded() || e->veh[b].is_parked)) {
+        int bt = -1;
+        for (int c : path) if (e->occ[c] == 0) { bt = c; break; }
+        if (bt >= 0) {
+          astar(e, sx, sy, bt % W, bt / W, false, true, P.max_contraflow_overtake_steps, bypass);
+          if (!bypass.empty() && bypass.back() == bt && bypass.size() > 1) {
+            int idx_bp = -1;
+            for (size_t i = 0; i < path.size(); i++) if (path[i] == bt) { idx_bp = (int)i; break; }
+            if (idx_bp >= 0) {
+              v.pre_overtake_path = path;
+              v.overtake_path = bypass; v.overtake_path_none = false;
+              out = bypass;
+              out.insert(out.end(), path.begin() + idx_bp + 1, path.end());
+              v.is_overtaking = true;
+              e->C.overtaking++;
+              v.overtaking_duration = 0;
+              return;
+            }
+          }
+        }
+      }
+    }
+  }
+  // Phase 4: stuck detour (369-418)
+  if (P.stuck_contraflow_enabled && !path.empty()) {
+    int threshold = e->intersection[v.pos] == 1 ? P.stuck_contraflow_threshold_intersection
+                                                : P.stuck_contraflow_threshold;
+    if (v.stuck_ticks >= threshold) {
+      int bt = -1;
+      for (int c : path) if (e->occ[c] == 0) { bt = c; break; }
+      if (bt >= 0) {
+        astar(e, sx, sy, bt % W, bt / W, true, true, P.max_contraflow_stuck_detour_steps, bypass);
+        if (!bypass.empty() && bypass.back() == bt && bypass.size() > 1) {
+          int merge_idx = -1;
+          for (size_t i = 0; i < path.size(); i++) if (path[i] == bt) { merge_idx = (int)i; break; }
+          if (merge_idx >= 0) {
+            v.pre_stuck_detour_path = path;
+            v.stuck_detour_path = bypass; v.stuck_detour_path_none = false;
+            out = bypass;
+            out.insert(out.end(), path.begin() + merge_idx + 1, path.end());
+            e->C.in_stuck_detour++;
+            v.is_in_stuck_detour = true;
+            v.stuck_detour_duration = 0;
+            return;
+          }
+        }
+      }
+      out = path;
+      return;
+    }
+  }
+  out = path;
+}
+
+// _compute_path (vehicle_base.py:143-167)
+void compute_path(E* e, int vid, bool use_cache, std::vector<int>& out) {
+  Vehicle& v = e->veh[vid];
+  v.cooldown = e->P.pathfinding_cooldown;
+  uint64_t key = ((uint64_t)(uint32_t)v.pos << 32) | (uint32_t)v.target;
+  if (use_cache && e->P.pathfinding_cache) {
+    auto it = e->path_cache.find(key);
+    if (it != e->path_cache.end()) { out = it->second; return; }
+  }
+  compute_path_internal(e, vid, out);
+  if (use_cache && e->P.pathfinding_cache && !out.empty() && !v.is_overtaking && !v.is_in_stuck_detour)
+    e->path_cache[key] = out;
+}
+
+inline void set_path(Vehicle& v, std::vector<int>& p) { v.path.swap(p); v.head = 0; }
+
+// _check_sideswipe_collision (vehicle_base.py:567-605)
+void check_sideswipe(E* e, int vid) {
+  Vehicle& v = e->veh[vid];
+  if (!e->P.sideswipe_active || v.direction < 0) return;
+  const int W = e->W, H = e->H;
+  const int left_dir = (v.direction + 3) & 3, right_dir = (v.direction + 1) & 3;
+  const int opposite = (v.direction + 2) & 3;
+  const int lat[2] = {left_dir, right_dir};
+  int x = v.pos % W, y = v.pos / W;
+  for (int k = 0; k < 2; k++) {
+    int nx = x + DX[lat[k]], ny = y + DY[lat[k]];
+    if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
+    for (int a = e->cell_head[ny * W + nx]; a >= 0; a = e->veh[a].next_in_cell) {
+      Vehicle& ag = e->veh[a];
+      if (ag.current_speed <= 0 || ag.is_stuck || ag.is_parked || ag.is_in_collision || ag.is_in_malfunction)
+        continue;
+      if (ag.direction != opposite) continue;
+      if (e->rng_global.random() >= e->P.sideswipe_chance) return;
+      set_collision(e, v, e->P.sideswipe_duration);
+      set_collision(e, ag, e->P.sideswipe_duration);
+      return;
+    }
+  }
+}
+
+// _recompute_path_on_obstacle (vehicle_base.py:454-504)
+void recompute_on_obstacle(E* e, int vid, int& idx_stop, int& idx_vehicle) {
+  Vehicle& v = e->veh[vid];
+  const TsParams& P = e->P;
+  if (v.is_overtaking && (v.overtake_path_none || v.overtake_path.empty() || !contains(v.overtake_path, v.pos))) {
+    v.overtake_path.clear(); v.overtake_path_none = true; v.is_overtaking = false;
+  }
+  if (v.is_in_stuck_detour &&
+      (v.stuck_detour_path_none || v.stuck_detour_path.empty() || !contains(v.stuck_detour_path, v.pos))) {
+    v.stuck_detour_path.clear(); v.stuck_detour_path_none = true; v.is_in_stuck_detour = false;
+  }
+  scan_ahead(e, v, idx_stop, idx_vehicle);
+  if (v.is_overtaking) {
+    v.overtaking_duration += 1;
+    if (v.overtaking_duration <= P.contraflow_overtake_duration) return;
+  }
+  if (v.is_in_stuck_detour) {
+    v.stuck_detour_duration += 1;
+    if (v.stuck_detour_duration <= P.contraflow_stuck_detour_duration) return;
+  }
+  if (v.cooldown > 0) {
+    if (idx_vehicle == 0) {
+      int b = first_vehicle_on_cell(e, v.path[v.head]);
+      if (b >= 0 && (e->veh[b].stranded() || e->veh[b].is_parked)) {
+        // immediate pathfinding
+      } else { v.cooldown -= 1; return; }
+    } else { v.cooldown -= 1; return; }
+  }
+  if (idx_stop >= 0 || idx_vehicle >= 0) {
+    std::vector<int> p;
+    compute_path(e, vid, false, p);
+    if (!p.empty()) {
+      set_path(v, p);
+      scan_ahead(e, v, idx_stop, idx_vehicle);
+    }
+  }
+}
+
+// step_decide (vehicle_base.py:616-663); returns true if the vehicle removed itself
+bool step_decide(E* e, int vid) {
+  Vehicle& v = e->veh[vid];
+  const TsParams& P = e->P;
+  v.early_exit = false;
+  if (tick_stranded(e, v)) { v.base_speed = 0; v.current_speed = 0; v.early_exit = true; return false; }
+  // _check_malfunction (608-610): `not ACTIVE or random() < CHANCE` (short-circuit: no draw when inactive)
+  if (!P.malfunction_active || e->rng_global.random() < P.malfunction_chance)
+    set_malfunction(e, v, P.malfunction_duration);
+  if (v.stranded()) { v.base_speed = 0; v.current_speed = 0; v.early_exit = true; return false; }
+  check_sideswipe(e, vid);
+  if (v.stranded()) { v.base_speed = 0; v.current_speed = 0; v.early_exit = true; return false; }
+  if (e->stop[v.pos] == 1) { v.base_speed = 0; v.current_speed = 0; v.early_exit = true; return false; }
+  // _compute_speed (94-112)
+  if (v.base_speed == 0) v.base_speed = e->rng_global.randint(P.vehicle_min_speed, P.vehicle_max_speed);
+  int speed = v.base_speed;
+  if (P.rain_enabled && e->rain[v.pos] == 1) speed = std::max(1, speed - P.rain_speed_reduction);
+  v.current_speed = speed;
+  // _recompute_path_on_stuck (506-517)
+  {
+    int thresh = e->intersection[v.pos] == 1 ? P.stuck_recompute_threshold_intersection : P.stuck_recompute_threshold;
+    if (v.stuck_ticks >= thresh) {
+      std::vector<int> p;
+      compute_path(e, vid, false, p);
+      set_path(v, p);
+    }
+  }
+  int idx_stop, idx_vehicle;
+  recompute_on_obstacle(e, vid, idx_stop, idx_vehicle);
+  // _determine_max_steps (719-731)
+  int max_steps = std::min<int>(v.current_speed, (int)v.plen());
+  bool blocked = false;
+  if (idx_stop >= 0) max_steps = std::min(max_steps, idx_stop);
+  if (idx_vehicle >= 0) {
+    if (idx_vehicle == 0) blocked = true;
+    max_steps = std::min(max_steps, idx_vehicle);
+  }
+  v.max_steps = max_steps; v.blocked_by_vehicle = blocked;
+  if (max_steps <= 0) {
+    v.base_speed = 0;
+    bool removed = false;
+    if (v.pos == v.target) { on_target_reached(e, vid); removed = !e->veh[vid].alive; }
+    e->veh[vid].early_exit = true;
+    return removed;
+  }
+  v.early_exit = false;
+  return false;
+}
+
+// _move_to (521-532) + CityModel.move_vehicle (city_model.py:1945-1963)
+void move_to(E* e, int vid, int new_pos) {
+  Vehicle& v = e->veh[vid];
+  int old_pos = v.pos;
+  e->occ[old_pos] = 0;
+  cell_remove(e, old_pos, vid);
+  cell_append(e, new_pos, vid);
+  e->occ[new_pos] = 1;
+  e->stuck[old_pos] = 0;
+  e->stuck[new_pos] = v.is_stuck ? 1 : 0;
+  v.pos = new_pos;
+  int dx = new_pos % e->W - old_pos % e->W, dy = new_pos / e->W - old_pos / e->W;
+  int dir = -1;  // compute_direction (numba_utilities.py:14-28)
+  if (dx == 0 && dy == 1) dir = 0; else if (dx == 1 && dy == 0) dir = 1;
+  else if (dx == 0 && dy == -1) dir = 2; else if (dx == -1 && dy == 0) dir = 3;
+  if (dir != -1) v.direction = dir;
+  if (v.stuck_ticks > 0) {
+    if (v.is_stuck) { e->C.stuck--; v.is_stuck = false; }
+    v.stuck_ticks = 0;
+  }
+}
+
+// VehicleAgent.step with PATHFINDING_BATCHING=True (vehicle_base.py:666-685)
+void vehicle_step(E* e, int vid) {
+  Vehicle& v = e->veh[vid];
+  e->C.agent_steps++;
+  if (!v.early_exit) {
+    // _execute_movement (733-753)
+    for (int step_idx = 0; step_idx < v.max_steps; step_idx++) {
+      if (v.plen() == 0) break;
+      int c = v.path[v.head];
+      if (e->occ[c] == 1 && c != v.pos) break;
+      if (e->stop[c] == 1 && step_idx != v.max_steps - 1) break;  // tuple `is not` => always true (746)
+      move_to(e, vid, c);
+      v.steps_traveled++;
+      v.head++;
+    }
+    v.has_prev = true;  // previous_pos = pos (677)
+  } else {
+    v.early_exit = false;
+    // tick_stuck (687-693)
+    if (v.has_prev && e->stop[v.pos] != 1) {
+      v.stuck_ticks++;
+      if (v.stuck_ticks > e->P.stuck_recompute_threshold && !v.is_stuck) { e->C.stuck++; v.is_stuck = true; }
+    }
+  }
+  if (v.pos == v.target) on_target_reached(e, vid);
+  // _despawn_check (695-706): VEHICLE_STUCK_DESPAWN_ENABLED = False (config.py:315); not restated.
+}
+
+// ------------------------------ light groups ---------------------------------------------------
+void light_set(E* e, int light, int8_t val) {  // CellAgent.set_light_stop/go (cell.py:241-251)
+  e->stop[e->light_cell[light]] = val;
+  for (int c : e->light_ctrl[light]) e->stop[c] = val;
+}
+inline int queue_sum(E* e, const std::vector<int>& cells) {  // compute_approach_queue (numba_utilities.py:65-72)
+  int q = 0;
+  for (int c : cells) q += e->occ[c];
+  return q;
+}
+void apply_phase(Group& g, int phase) {  // intersection_light_group.py:386-393
+  if (phase == g.current_phase || phase == g.pending_phase) return;
+  g.pending_phase = phase;
+}
+void group_step(E* e, int gi) {  // IntersectionLightGroup.step (396-423)
+  Group& g = e->groups[gi];
+  const TsParams& P = e->P;
+  if (g.pending_phase < 0) {
+    switch (P.light_algorithm) {
+      case TS_LIGHTS_FIXED_TIME:  // run_fixed_time (427-441)
+        g.fixed_time_timer += 1;
+        if (g.fixed_time_timer == 1) apply_phase(g, g.ft_phase);
+        if (g.fixed_time_timer >= P.green_duration) { g.ft_phase = 1 - g.ft_phase; g.fixed_time_timer = 0; }
+        break;
+      case TS_LIGHTS_QUEUE_ACTUATED: {  // run_queue_actuated (463-494)
+        g.queue_timer += 1;
+        int ns_q = queue_sum(e, g.ns_in), ew_q = queue_sum(e, g.ew_in);
+        int current_q, opp_q;
+        if (g.current_phase == 0) { current_q = ns_q; opp_q = ew_q; } else { current_q = ew_q; opp_q = ns_q; }
+        if (g.queue_timer == 1) { g.last_arrival = current_q; g.gap_timer = 0; }
+        if (current_q > g.last_arrival) { g.last_arrival = current_q; g.gap_timer = 0; }
+        else g.gap_timer += 1;
+        if (g.queue_timer >= P.qa_min_green &&
+            (g.gap_timer >= P.qa_gap || g.queue_timer >= P.qa_max_green || (opp_q > current_q && current_q == 0))) {
+          apply_phase(g, 1 - g.current_phase);
+          g.queue_timer = 0;
+        }
+        break;
+      }
+      case TS_LIGHTS_PRESSURE_CONTROL:            // run_pressure_control (448-461): raises in the reference
+      case TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL: { // run_neighbor_pressure_control (496-519)
+        int ns_p = queue_sum(e, g.ns_in) - queue_sum(e, g.ns_out);
+        int ew_p = queue_sum(e, g.ew_in) - queue_sum(e, g.ew_out);
+        if (P.light_algorithm == TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL) {
+          const int* nd = g.links_repopulated ? g.nb_dir : g.nb_dir_ctor;
+          const int* ngp = g.links_repopulated ? g.nb_grp : g.nb_grp_ctor;
+          for (int k = 0; k < 4; k++) {
+            if (nd[k] < 0 || ngp[k] < 0) continue;
+            const Group& n = e->groups[ngp[k]];
+            if (nd[k] == 0 || nd[k] == 2) ns_p -= n.ns_pressure; else ew_p -= n.ew_pressure;
+          }
+        }
+        g.ns_pressure = ns_p; g.ew_pressure = ew_p;
+        apply_phase(g, ns_p > ew_p ? 0 : 1);
+        break;
+      }
+      case TS_LIGHTS_NEIGHBOR_GREEN_WAVE: {  // run_neighbor_green_wave (521-546)
+        int ns_q = queue_sum(e, g.ns_in), ew_q = queue_sum(e, g.ew_in);
+        bool favor_ns = false, favor_ew = false;
+        const int* nd = g.links_repopulated ? g.nb_dir : g.nb_dir_ctor;
+        const int* ngp = g.links_repopulated ? g.nb_grp : g.nb_grp_ctor;
+        for (int k = 0; k < 4; k++) {
+          if (nd[k] < 0 || ngp[k] < 0) continue;
+          const Group& n = e->groups[ngp[k]];
+          if ((nd[k] == 0 || nd[k] == 2) && n.current_phase == 0) favor_ns = true;
+          if ((nd[k] == 1 || nd[k] == 3) && n.current_phase == 1) favor_ew = true;
+        }
+        if (favor_ns && !favor_ew) apply_phase(g, 0);
+        else if (favor_ew && !favor_ns) apply_phase(g, 1);
+        else apply_phase(g, ns_q > ew_q ? 0 : 1);
+        break;
+      }
+      default: break;
+    }
+  }
+  // _execute_phase_change (348-384)
+  if (g.pending_phase < 0) return;
+  if (P.transition_duration_enabled && g.transition_timer > 0) {
+    g.transition_timer -= 1;
+    for (int l : g.lights) light_set(e, l, 1);
+    return;
+  }
+  if (P.transition_clearance_enabled) {
+    bool occupied = false;  // is_intersection_occupied (285-291)
+    for (int c : g.icells) if (e->occ[c]) { occupied = true; break; }
+    if (occupied) { for (int l : g.lights) light_set(e, l, 1); return; }
+  }
+  if (P.transition_duration_enabled && g.clearance_timer > 0) g.transition_timer = P.all_red_duration;
+  // get_opposite_traffic_lights() (303-307): opposite_pairs is empty after construction, so the first
+  // call re-runs populate_links(); from then on ns/ew lights and neighbor_groups are complete
+  g.links_repopulated = true;
+  if (g.pending_phase == 0) {
+    for (int l : g.ns_lights) light_set(e, l, 0);
+    for (int l : g.ew_lights) light_set(e, l, 1);
+  } else {
+    for (int l : g.ew_lights) light_set(e, l, 0);
+    for (int l : g.ns_lights) light_set(e, l, 1);
+  }
+  g.current_phase = g.pending_phase;
+  g.pending_phase = -1;
+}
+
+// ------------------------------ one tick (city_model.py:1831-1860) -----------------------------
+void tick(E* e) {
+  // _update_density_map (1853): the map is a function of the occupancy at this point; it is
+  // materialised lazily from a snapshot unless eager_density asks for the reference's cost profile
+  e->occ_snap = e->occ;
+  e->density_valid = false;
+  if (e->P.eager_density) update_density_fast(e);
+  // run_parallel_decide with one worker (1811-1829): list order; removing the current element while
+  // the generator iterates the live list makes the iterator skip the following element.
+  {
+    size_t w = 0;
+    for (size_t i = 0; i < e->active.size(); i++) if (e->active[i] >= 0) e->active[w++] = e->active[i];
+    e->active.resize(w);
+    bool skip_next = false;
+    for (size_t i = 0; i < e->active.size(); i++) {
+      int vid = e->active[i];
+      if (vid < 0) continue;
+      if (skip_next) { skip_next = false; continue; }
+      if (step_decide(e, vid)) skip_next = true;
+    }
+  }
+  // RandomActivation.step: keys in insertion order, shuffled with model.random
+  std::vector<int> keys;
+  keys.reserve(e->sched.size());
+  {
+    size_t w = 0;
+    bool any_dead = false;
+    for (size_t i = 0; i < e->sched.size(); i++) if (!e->sched[i].alive) { any_dead = true; break; }
+    if (any_dead) {
+      for (size_t i = 0; i < e->sched.size(); i++) {
+        if (e->sched[i].alive) {
+          if (e->sched[i].kind == 100) e->veh_sched[e->sched[i].ref] = (int)w;
+          e->sched[w++] = e->sched[i];
+        }
+      }
+      e->sched.resize(w);
+    }
+  }
+  for (size_t i = 0; i < e->sched.size(); i++) keys.push_back((int)i);
+  for (int i = (int)keys.size() - 1; i >= 1; i--) {  // random.shuffle
+    uint32_t j = e->rng_sched.randbelow((uint32_t)(i + 1));
+    std::swap(keys[i], keys[j]);
+  }
+  for (int k : keys) {
+    SchedEntry se = e->sched[k];
+    if (!se.alive) continue;
+    switch (se.kind) {
+      case 100: vehicle_step(e, se.ref); break;
+      case TS_AGENT_LIGHT_GROUP: group_step(e, se.ref); break;
+      case TS_AGENT_CLOCK: e->C.elapsed += e->P.time_per_step_seconds; break;
+      default: break;
+    }
+  }
+  e->C.step_count++;
+}
+
+uint32_t path_crc(E* e, const Vehicle& v) {
+  if (v.plen() == 0) return 0;
+  uint32_t crc = 0xFFFFFFFFU;
+  for (size_t i = v.head; i < v.path.size(); i++) {
+    int32_t xy[2] = {v.path[i] % e->W, v.path[i] / e->W};
+    crc = crc_update(crc, xy, 8);
+  }
+  return crc ^ 0xFFFFFFFFU;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI (same signatures as include/trafficsim.h, prefix tso_)
+// =============================================================================================
+extern "C" {
+
+void tso_default_params(TsParams* p) {
+  memset(p, 0, sizeof(*p));
+  p->vehicle_min_speed = 1; p->vehicle_max_speed = 5; p->vehicle_awareness_range = 10;
+  p->rain_enabled = 1; p->rain_speed_reduction = 2;
+  p->pathfinding_cooldown = 5; p->pathfinding_cache = 1;
+  p->stuck_recompute_threshold = 30; p->stuck_recompute_threshold_intersection = 1;
+  p->contraflow_overtake_active = 1; p->max_contraflow_overtake_steps = 6; p->contraflow_overtake_duration = 30;
+  p->stuck_contraflow_enabled = 1; p->stuck_contraflow_threshold = 60; p->stuck_contraflow_threshold_intersection = 10;
+  p->max_contraflow_stuck_detour_steps = 20; p->contraflow_stuck_detour_duration = 10;
+  p->malfunction_active = 1; p->malfunction_duration = 400; p->malfunction_chance = 1e-7;
+  p->sideswipe_active = 1; p->sideswipe_duration = 600; p->sideswipe_chance = 1e-9;
+  p->contraflow_penalty = 5000; p->obstacle_penalty_vehicle = 1000; p->obstacle_penalty_stop = 500;
+  p->road_type_penalties_enabled = 1; p->turn_penalty_enabled = 1; p->turn_penalty = 10;
+  p->dynamic_penalties_enabled = 1;
+  p->road_type_penalty_r1 = 0.5; p->road_type_penalty_r2 = 5; p->road_type_penalty_r3 = 50.0;
+  p->dynamic_penalty_scale = 4.0;
+  p->light_algorithm = TS_LIGHTS_QUEUE_ACTUATED;
+  p->transition_duration_enabled = 0; p->transition_clearance_enabled = 1; p->all_red_duration = 2;
+  p->green_duration = 20; p->qa_min_green = 5; p->qa_max_green = 30; p->qa_gap = 3;
+  p->enable_traffic = 1; p->time_per_step_seconds = 6; p->eager_density = 0;
+}
+
+int tso_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
+  if (!w || !params || !out || w->width <= 0 || w->height <= 0 || !w->allowed_dirs_map || !w->is_road_map ||
+      !w->road_type_map || !w->intersection_map)
+    return TS_E_INVALID;
+  if (!crc_init_done) crc_init();
+  E* e = new E();
+  e->W = w->width; e->H = w->height; e->N = w->width * w->height;
+  e->P = *params;
+  size_t N = e->N;
+  e->allowed.assign(w->allowed_dirs_map, w->allowed_dirs_map + N);
+  e->is_road.assign(w->is_road_map, w->is_road_map + N);
+  e->road_type.assign(w->road_type_map, w->road_type_map + N);
+  e->intersection.assign(w->intersection_map, w->intersection_map + N);
+  e->occ.assign(N, 0); e->stop.assign(N, 0); e->stuck.assign(N, 0); e->rain.assign(N, 0);
+  e->cell_head.assign(N, -1);
+  e->occ_snap.assign(N, 0);  // harness rule: _update_density_map() on the fresh (empty) model
+  memset(&e->C, 0, sizeof(e->C));
+  *out = e;
+  return TS_OK;
+}
+
+int tso_destroy(ts_handle h) { delete h; return TS_OK; }
+const char* tso_last_error(ts_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int tso_set_lights(ts_handle e, const TsLightTables* t) {
+  if (!e || !t) return TS_E_INVALID;
+  const int W = e->W, H = e->H;
+  auto cell = [&](const int32_t* xy, int i, int& out) {
+    int x = xy[2 * i], y = xy[2 * i + 1];
+    if (x < 0 || x >= W || y < 0 || y >= H) return false;
+    out = y * W + x;
+    return true;
+  };
+  e->groups.assign(t->n_groups, Group());
+  e->light_cell.assign(t->n_lights, 0);
+  e->light_ctrl.assign(t->n_lights, {});
+  for (int l = 0; l < t->n_lights; l++) {
+    if (!cell(t->light_xy, l, e->light_cell[l])) return fail(e, TS_E_INVALID, "light cell out of bounds");
+    for (int k = t->light_ctrl_off[l]; k < t->light_ctrl_off[l + 1]; k++) {
+      int c;
+      if (!cell(t->light_ctrl_xy, k, c)) return fail(e, TS_E_INVALID, "controlled block out of bounds");
+      e->light_ctrl[l].push_back(c);
+    }
+  }
+  auto fill = [&](std::vector<int>& dst, const int32_t* off, const int32_t* xy, int g) {
+    for (int k = off[g]; k < off[g + 1]; k++) {
+      int c;
+      if (!cell(xy, k, c)) return false;
+      dst.push_back(c);
+    }
+    return true;
+  };
+  for (int g = 0; g < t->n_groups; g++) {
+    Group& G = e->groups[g];
+    for (int l = t->g_light_off[g]; l < t->g_light_off[g + 1]; l++) G.lights.push_back(l);
+    for (int k = t->g_ns_off[g]; k < t->g_ns_off[g + 1]; k++) G.ns_lights.push_back(t->g_ns[k]);
+    for (int k = t->g_ew_off[g]; k < t->g_ew_off[g + 1]; k++) G.ew_lights.push_back(t->g_ew[k]);
+    if (!fill(G.icells, t->g_icell_off, t->g_icell_xy, g) || !fill(G.ns_in, t->g_ns_in_off, t->g_ns_in_xy, g) ||
+        !fill(G.ns_out, t->g_ns_out_off, t->g_ns_out_xy, g) || !fill(G.ew_in, t->g_ew_in_off, t->g_ew_in_xy, g) ||
+        !fill(G.ew_out, t->g_ew_out_off, t->g_ew_out_xy, g))
+      return fail(e, TS_E_INVALID, "group cell out of bounds");
+    for (int k = 0; k < 4; k++) {
+      G.nb_dir[k] = t->g_neighbors ? t->g_neighbors[(g * 4 + k) * 2] : -1;
+      G.nb_grp[k] = t->g_neighbors ? t->g_neighbors[(g * 4 + k) * 2 + 1] : -1;
+      const int32_t* nc = t->g_neighbors_ctor ? t->g_neighbors_ctor : t->g_neighbors;
+      G.nb_dir_ctor[k] = nc ? nc[(g * 4 + k) * 2] : -1;
+      G.nb_grp_ctor[k] = nc ? nc[(g * 4 + k) * 2 + 1] : -1;
+      if (G.nb_grp[k] >= t->n_groups || G.nb_grp_ctor[k] >= t->n_groups)
+        return fail(e, TS_E_INVALID, "neighbor group index out of range");
+    }
+    // __init__: apply_phase(self._ft_phase) unless DISABLED (intersection_light_group.py:115-116)
+    if (e->P.light_algorithm != TS_LIGHTS_DISABLED) apply_phase(G, G.ft_phase);
+  }
+  e->groups_scheduled = 0;
+  return TS_OK;
+}
+
+int tso_schedule_add(ts_handle e, int32_t kind, int32_t count) {
+  if (!e || count < 0) return TS_E_INVALID;
+  for (int i = 0; i < count; i++) {
+    SchedEntry se{kind, 0, true};
+    if (kind == TS_AGENT_LIGHT_GROUP) {
+      if (e->groups_scheduled >= (int)e->groups.size()) return fail(e, TS_E_INVALID, "more group slots than groups");
+      se.ref = e->groups_scheduled++;
+    } else if (kind != TS_AGENT_NOOP && kind != TS_AGENT_CLOCK) return fail(e, TS_E_INVALID, "bad agent kind");
+    e->sched.push_back(se);
+  }
+  return TS_OK;
+}
+
+int tso_seed(ts_handle e, int32_t stream, const uint32_t* mt, uint32_t index) {
+  if (!e || !mt || stream < 0 || stream > 1 || index > 624) return TS_E_INVALID;
+  MT& r = stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched;
+  memcpy(r.mt, mt, sizeof(r.mt)); r.idx = index;
+  e->seeded[stream] = true;
+  return TS_OK;
+}
+int tso_seed_int(ts_handle e, int32_t stream, uint64_t seed) {
+  if (!e || stream < 0 || stream > 1) return TS_E_INVALID;
+  (stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched).seed_int(seed);
+  e->seeded[stream] = true;
+  return TS_OK;
+}
+int tso_rng_state(ts_handle e, int32_t stream, uint32_t* mt_out, uint32_t* index_out) {
+  if (!e || stream < 0 || stream > 1 || !mt_out || !index_out) return TS_E_INVALID;
+  MT& r = stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched;
+  memcpy(mt_out, r.mt, sizeof(r.mt)); *index_out = r.idx;
+  return TS_OK;
+}
+
+int tso_add_vehicles(ts_handle e, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
+                     const int32_t* population_type, const int32_t* path_off, const int32_t* path_xy) {
+  if (!e || n < 0 || (n > 0 && (!start_xy || !goal_xy))) return TS_E_INVALID;
+  const int W = e->W, H = e->H;
+  for (int i = 0; i < n; i++) {
+    int sx = start_xy[2 * i], sy = start_xy[2 * i + 1], gx = goal_xy[2 * i], gy = goal_xy[2 * i + 1];
+    if (sx < 0 || sx >= W || sy < 0 || sy >= H || gx < 0 || gx >= W || gy < 0 || gy >= H)
+      return fail(e, TS_E_INVALID, "vehicle start/goal out of bounds");
+    if (path_off) {
+      int px = sx, py = sy;
+      for (int k = path_off[i]; k < path_off[i + 1]; k++) {
+        int x = path_xy[2 * k], y = path_xy[2 * k + 1];
+        if (x < 0 || x >= W || y < 0 || y >= H || std::abs(x - px) + std::abs(y - py) != 1)
+          return fail(e, TS_E_INVALID, "explicit path is not a 4-adjacent in-bounds chain");
+        px = x; py = y;
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    Vehicle v;
+    int vid = (int)e->veh.size();
+    v.spawn_idx = vid;
+    v.pos = start_xy[2 * i + 1] * W + start_xy[2 * i];
+    v.target = goal_xy[2 * i + 1] * W + goal_xy[2 * i];
+    v.pop_type = population_type ? population_type[i] : TS_POP_UNDEFINED;
+    v.depart_time = e->P.enable_traffic ? e->C.elapsed : 0.0;
+    e->veh.push_back(v);
+    // place_vehicle (city_model.py:1897-1918)
+    e->active.push_back(vid);
+    cell_append(e, e->veh[vid].pos, vid);
+    e->occ[e->veh[vid].pos] = 1;
+    e->stuck[e->veh[vid].pos] = 0;
+    e->veh_sched.push_back((int)e->sched.size());
+    e->sched.push_back(SchedEntry{100, vid, true});
+    if (e->veh[vid].pop_type == TS_POP_INTERNAL) e->C.live_internal++;
+    else if (e->veh[vid].pop_type == TS_POP_THROUGH) e->C.live_through++;
+    // self.path = self._compute_path() (vehicle_base.py:80-81)
+    std::vector<int> p;
+    if (path_off) {
+      e->veh[vid].cooldown = e->P.pathfinding_cooldown;
+      for (int k = path_off[i]; k < path_off[i + 1]; k++) p.push_back(path_xy[2 * k + 1] * W + path_xy[2 * k]);
+    } else {
+      compute_path(e, vid, true, p);
+    }
+    set_path(e->veh[vid], p);
+  }
+  return TS_OK;
+}
+
+int tso_upload_map(ts_handle e, int32_t which, const int8_t* src) {
+  if (!e || !src) return TS_E_INVALID;
+  std::vector<int8_t>* m = which == TS_MAP_STOP ? &e->stop : which == TS_MAP_RAIN ? &e->rain : nullptr;
+  if (!m) return fail(e, TS_E_INVALID, "only stop_map and rain_map are host-writable");
+  memcpy(m->data(), src, e->N);
+  return TS_OK;
+}
+
+int tso_step(ts_handle e, int32_t n_ticks) {
+  if (!e || n_ticks < 0) return TS_E_INVALID;
+  if (!e->seeded[0] || !e->seeded[1]) return fail(e, TS_E_STATE, "both RNG streams must be seeded before step");
+  for (int t = 0; t < n_ticks; t++) tick(e);
+  return TS_OK;
+}
+
+int tso_num_vehicles(ts_handle e) {
+  int n = 0;
+  for (int v : e->active) if (v >= 0) n++;
+  return n;
+}
+int tso_num_groups(ts_handle e) { return (int)e->groups.size(); }
+int tso_num_scheduled(ts_handle e) {
+  int n = 0;
+  for (auto& s : e->sched) if (s.alive) n++;
+  return n;
+}
+
+int tso_download_map(ts_handle e, int32_t which, int8_t* dst) {
+  if (!e || !dst) return TS_E_INVALID;
+  const std::vector<int8_t>* m = which == TS_MAP_OCCUPANCY ? &e->occ : which == TS_MAP_STOP ? &e->stop
+                               : which == TS_MAP_STUCK ? &e->stuck : which == TS_MAP_RAIN ? &e->rain : nullptr;
+  if (!m) return TS_E_INVALID;
+  memcpy(dst, m->data(), e->N);
+  return TS_OK;
+}
+int tso_download_density(ts_handle e, float* dst) {
+  if (!e || !dst) return TS_E_INVALID;
+  std::vector<int8_t> keep = e->occ_snap;
+  e->occ_snap = e->occ;
+  update_density(e);
+  memcpy(dst, e->density.data(), sizeof(float) * e->N);
+  e->occ_snap.swap(keep);
+  e->density_valid = false;
+  return TS_OK;
+}
+
+int tso_download_vehicles(ts_handle e, int32_t* rows, int32_t cap_rows) {
+  if (!e || !rows) return TS_E_INVALID;
+  int n = 0;
+  for (int vid : e->active) {
+    if (vid < 0) continue;
+    if (n >= cap_rows) return TS_E_CAPACITY;
+    const Vehicle& v = e->veh[vid];
+    int32_t* r = rows + (size_t)n * TS_V_NFIELDS;
+    r[TS_V_SPAWN_IDX] = v.spawn_idx; r[TS_V_X] = v.pos % e->W; r[TS_V_Y] = v.pos / e->W;
+    r[TS_V_BASE_SPEED] = v.base_speed; r[TS_V_CURRENT_SPEED] = v.current_speed; r[TS_V_MAX_STEPS] = v.max_steps;
+    r[TS_V_DIRECTION] = v.direction; r[TS_V_STUCK_TICKS] = v.stuck_ticks; r[TS_V_COOLDOWN] = v.cooldown;
+    int f = 0;
+    if (v.early_exit) f |= TS_F_EARLY_EXIT;
+    if (v.is_stuck) f |= TS_F_STUCK;
+    if (v.is_parked) f |= TS_F_PARKED;
+    if (v.is_in_collision) f |= TS_F_COLLISION;
+    if (v.is_in_malfunction) f |= TS_F_MALFUNCTION;
+    if (v.is_overtaking) f |= TS_F_OVERTAKING;
+    if (v.is_in_stuck_detour) f |= TS_F_DETOUR;
+    if (v.blocked_by_vehicle) f |= TS_F_BLOCKED;
+    if (v.has_prev) f |= TS_F_HAS_PREV;
+    r[TS_V_FLAGS] = f; r[TS_V_STRANDED_LEFT] = v.stranded_left; r[TS_V_STEPS_TRAVELED] = v.steps_traveled;
+    r[TS_V_PATH_LEN] = (int)v.plen(); r[TS_V_PATH_CRC] = (int32_t)path_crc(e, v);
+    r[TS_V_OVERTAKE_DUR] = v.overtaking_duration; r[TS_V_DETOUR_DUR] = v.stuck_detour_duration;
+    n++;
+  }
+  return n;
+}
+
+int tso_download_path(ts_handle e, int32_t active_pos, int32_t* xy, int32_t cap_cells) {
+  if (!e) return TS_E_INVALID;
+  int n = 0;
+  for (int vid : e->active) {
+    if (vid < 0) continue;
+    if (n == active_pos) {
+      const Vehicle& v = e->veh[vid];
+      int len = (int)v.plen();
+      if (xy) {
+        if (len > cap_cells) return TS_E_CAPACITY;
+        for (int i = 0; i < len; i++) { xy[2 * i] = v.path[v.head + i] % e->W; xy[2 * i + 1] = v.path[v.head + i] / e->W; }
+      }
+      return len;
+    }
+    n++;
+  }
+  return TS_E_INVALID;
+}
+
+int tso_download_groups(ts_handle e, int32_t* rows) {
+  if (!e || !rows) return TS_E_INVALID;
+  for (size_t g = 0; g < e->groups.size(); g++) {
+    const Group& G = e->groups[g];
+    int32_t* r = rows + g * TS_G_NFIELDS;
+    r[TS_G_CURRENT_PHASE] = G.current_phase; r[TS_G_PENDING_PHASE] = G.pending_phase;
+    r[TS_G_QUEUE_TIMER] = G.queue_timer; r[TS_G_GAP_TIMER] = G.gap_timer; r[TS_G_LAST_ARRIVAL] = G.last_arrival;
+    r[TS_G_FIXED_TIME_TIMER] = G.fixed_time_timer; r[TS_G_FT_PHASE] = G.ft_phase;
+    r[TS_G_NS_PRESSURE] = G.ns_pressure; r[TS_G_EW_PRESSURE] = G.ew_pressure;
+  }
+  return (int)e->groups.size();
+}
+
+int tso_counters(ts_handle e, TsCounters* out) {
+  if (!e || !out) return TS_E_INVALID;
+  *out = e->C;
+  return TS_OK;
+}
+
+int tso_astar(ts_handle e, int32_t sx, int32_t sy, int32_t gx, int32_t gy, int32_t soft, int32_t ignore_flow,
+              int32_t maximum_steps, int32_t* out_xy, int32_t cap_cells) {
+  if (!e) return TS_E_INVALID;
+  if (sx < 0 || sx >= e->W || sy < 0 || sy >= e->H || gx < 0 || gx >= e->W || gy < 0 || gy >= e->H)
+    return fail(e, TS_E_INVALID, "astar endpoints out of bounds");
+  std::vector<int> p;
+  std::vector<int8_t> keep;
+  if (soft) { keep = e->occ_snap; e->occ_snap = e->occ; update_density(e); }
+  astar(e, sx, sy, gx, gy, soft != 0, ignore_flow != 0, maximum_steps, p);
+  if (soft) { e->occ_snap.swap(keep); e->density_valid = false; }
+  if ((int)p.size() > cap_cells) return TS_E_CAPACITY;
+  for (size_t i = 0; i < p.size(); i++) { out_xy[2 * i] = p[i] % e->W; out_xy[2 * i + 1] = p[i] / e->W; }
+  return (int)p.size();
+}
+
+/* test hook: write occupancy directly (A* KATs need an arbitrary occupancy map) */
+int tso_debug_set_occupancy(ts_handle e, const int8_t* src) {
+  if (!e || !src) return TS_E_INVALID;
+  memcpy(e->occ.data(), src, e->N);
+  return TS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,497 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (build container only; NEVER runs on the GPU box).
+
+Executes the reference's own, unmodified source files from /root/reference with the
+stand-in packages of tests/golden/standins (mesa / numba / tensorflow are not installed
+here; see standins/README.md and SURVEY.md §8(c)) and records small fixtures under
+tests/golden/*.npz:
+
+  G1  world tables  (static maps, light-group tables, schedule layout, entrances/exits)
+  G2  A* known-answer tests (astar_numba.py:243-281, all (soft, ignore_flow) modes)
+  G3  density map (city_model.py:1764-1778, real scipy.ndimage.uniform_filter)
+  G4  MT19937 streams from CPython's own `random` (random(), randint(1,5), shuffle)
+  G5  per-tick traces of CityModel.step() (maps, per-vehicle tuples, RNG fingerprints)
+  G6  per-tick light-group controller state
+
+Harness rules: cpu_count()=1 before import (sequential decide phase,
+deterministic); both RNG streams seeded (random.seed(s) and CityModel(seed=s));
+SAVE_*_RESULTS off; model._update_density_map() before the first VehicleAgent;
+density_map cast to float64 after each update so the un-jitted A* computes the soft
+penalty in float64 like numba does (astar_numba.py:199-200).
+
+Usage:  python tests/golden/make_golden.py all        (each scenario in a subprocess)
+        python tests/golden/make_golden.py <scenario>
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+# --------------------------------------------------------------------------------------
+# scenario table
+# --------------------------------------------------------------------------------------
+GATED = dict(PATHFINDING_COOLDOWN=10 ** 9, VEHICLE_STUCK_RECOMPUTE_THRESHOLD=10 ** 9,
+             VEHICLE_STUCK_RECOMPUTE_THRESHOLD_INTERSECTION=10 ** 9,
+             VEHICLE_CONTRAFLOW_OVERTAKE_ACTIVE=False, VEHICLE_STUCK_CONTRAFLOW_ENABLED=False)
+CLOSED = dict(RAIN_ENABLED=False, INTERNAL_POPULATION_TRAFFIC_PER_DAY=0,
+              PASSING_POPULATION_TRAFFIC_PER_DAY=0, TOTAL_SERVICE_VEHICLES_FOOD=0,
+              TOTAL_SERVICE_VEHICLES_WASTE=0)
+
+SCENARIOS = {
+    # config-2 style: car-following + move only (lights disabled, replans gated off)
+    "carfollow_64_s1": dict(size=64, seed=1, vehicles=60, ticks=80,
+                            defaults={**CLOSED, **GATED, "TRAFFIC_LIGHT_AGENT_ALGORITHM": "DISABLED"}),
+    "carfollow_96_s2": dict(size=96, seed=2, vehicles=400, ticks=60,
+                            defaults={**CLOSED, **GATED, "TRAFFIC_LIGHT_AGENT_ALGORITHM": "DISABLED"}),
+    "carfollow_128_s3": dict(size=128, seed=3, vehicles=900, ticks=50,
+                             defaults={**CLOSED, **GATED, "TRAFFIC_LIGHT_AGENT_ALGORITHM": "DISABLED"}),
+    # lights on (queue actuated), replans still gated off: isolates the light kernels
+    "lights_qa_96_s2": dict(size=96, seed=2, vehicles=300, ticks=120,
+                            defaults={**CLOSED, **GATED}),
+    "lights_fixed_64_s4": dict(size=64, seed=4, vehicles=60, ticks=100,
+                               defaults={**CLOSED, **GATED, "TRAFFIC_LIGHT_AGENT_ALGORITHM": "FIXED_TIME"}),
+    # NOTE: "PRESSURE_CONTROL" cannot be captured: run_pressure_control reshapes the occupancy map to
+    # (-1, 2) before indexing it as [y, x] (intersection_light_group.py:449-454) -> IndexError when the
+    # helper runs un-jitted (and an out-of-row read under numba).  Reference defect; parity unpinned.
+    "lights_npress_96_s6": dict(size=96, seed=6, vehicles=200, ticks=60,
+                                defaults={**CLOSED, **GATED,
+                                          "TRAFFIC_LIGHT_AGENT_ALGORITHM": "NEIGHBOR_PRESSURE_CONTROL"}),
+    "lights_gwave_96_s7": dict(size=96, seed=7, vehicles=200, ticks=60,
+                               defaults={**CLOSED, **GATED,
+                                         "TRAFFIC_LIGHT_AGENT_ALGORITHM": "NEIGHBOR_GREEN_WAVE"}),
+    # config-3 style: defaults (queue-actuated lights, full replanning policy), closed population
+    "full_64_s1": dict(size=64, seed=1, vehicles=50, ticks=120, defaults={**CLOSED}),
+    "full_96_s8": dict(size=96, seed=8, vehicles=250, ticks=80, defaults={**CLOSED}),
+    # strandings made frequent: malfunction / sideswipe / contraflow overtake / stuck detour paths
+    "faults_64_s9": dict(size=64, seed=9, vehicles=70, ticks=150,
+                         defaults={**CLOSED, "VEHICLE_MALFUNCTION_CHANCE": 0.004,
+                                   "VEHICLE_MALFUNCTION_DURATION": 25,
+                                   "VEHICLE_SIDESWIPE_COLLISION_CHANCE": 0.2,
+                                   "VEHICLE_SIDESWIPE_COLLISION_DURATION": 30}),
+    # config-5 style: sub-block roads + L-shaped carves
+    "carve_96_s10": dict(size=96, seed=10, vehicles=200, ticks=60,
+                         defaults={**CLOSED}, model_kwargs=dict(carve_subblock_roads=True)),
+    # config 1: everything on (rain, traffic generator, service vehicles) - "next" rows
+    "config1_64_s11": dict(size=64, seed=11, vehicles=50, ticks=100, defaults={}),
+}
+
+
+def _setup_paths():
+    import multiprocessing
+    multiprocessing.cpu_count = lambda: 1
+    sys.path.insert(0, os.path.join(HERE, "standins"))
+    sys.path.insert(1, REF)
+
+
+def _crc_path(path):
+    import numpy as np
+    if not path:
+        return 0
+    a = np.asarray(path, dtype=np.int32).reshape(-1, 2)
+    return zlib.crc32(a.tobytes()) & 0xFFFFFFFF
+
+
+def _rng_fp(state):
+    """(crc32 of the 624 key words, index) of a random.getstate() tuple."""
+    import numpy as np
+    words = np.asarray(state[1][:624], dtype=np.uint32)
+    return zlib.crc32(words.tobytes()) & 0xFFFFFFFF, int(state[1][624])
+
+
+DIRI = {"N": 0, "E": 1, "S": 2, "W": 3, None: -1}
+
+
+def world_tables(m):
+    """G1: everything the hot path consumes from world-gen."""
+    import numpy as np
+    from Simulation.agents.city_structure_entities.intersection_light_group import IntersectionLightGroup
+    from Simulation.agents.city_structure_entities.city_block import CityBlock
+    out = dict(
+        width=np.int32(m.width), height=np.int32(m.height),
+        allowed_dirs_map=m.allowed_dirs_map.copy(), is_road_map=m.is_road_map.copy(),
+        road_type_map=m.road_type_map.copy(), intersection_map=m.intersection_map.copy(),
+        stop_map0=m.stop_map.copy(),
+    )
+    groups = m.intersection_light_groups
+    gidx = {id(g): i for i, g in enumerate(groups)}
+    # ragged tables: (offsets[G+1], flat values)
+    def ragged(rows, width):
+        off = [0]
+        flat = []
+        for r in rows:
+            flat.extend(r)
+            off.append(len(flat) // width if width > 1 else len(flat))
+        arr = np.asarray(flat, dtype=np.int32)
+        if width > 1:
+            arr = arr.reshape(-1, width)
+        return np.asarray(off, dtype=np.int32), arr
+
+    light_rows, ctrl_rows_per_light = [], []
+    lights_flat = []          # every light of every group, in group.traffic_lights order
+    light_off = [0]
+    for g in groups:
+        for tl in g.traffic_lights:
+            lights_flat.append(tl)
+        light_off.append(len(lights_flat))
+    lidx = {id(tl): i for i, tl in enumerate(lights_flat)}
+    out["g_light_off"] = np.asarray(light_off, dtype=np.int32)
+    out["light_xy"] = np.asarray([tl.position for tl in lights_flat], dtype=np.int32).reshape(-1, 2)
+    out["light_ctrl_off"], out["light_ctrl_xy"] = ragged(
+        [[c for cb in tl.controlled_blocks for c in cb.position] for tl in lights_flat], 2)
+    # populate_links() runs inside the group constructor, BEFORE the model assigns
+    # cell.intersection_group (city_model.py:1639-1650), so at construction opposite_pairs is empty
+    # and neighbor_groups only sees earlier groups.  The first _execute_phase_change that reaches
+    # get_opposite_traffic_lights() (intersection_light_group.py:303-307, 369) re-runs
+    # populate_links() and the tables become complete.  Record both states without disturbing the
+    # model: "ctor" = as constructed, full = after re-population.
+    nb_ctor = np.full((len(groups), 4, 2), -1, dtype=np.int32)
+    for i, g in enumerate(groups):
+        for k, (d, ng) in enumerate((g.neighbor_groups or {}).items()):
+            nb_ctor[i, k] = (DIRI[d], gidx.get(id(ng), -1))
+        assert g.opposite_pairs == {"N-S": [], "W-E": []}, g.opposite_pairs
+    out["g_neighbors_ctor"] = nb_ctor
+    saved = [(g.neighbor_groups, g.intermediate_groups, g.opposite_pairs) for g in groups]
+    for g in groups:
+        g.populate_links()
+    out["g_ns_lights_off"], out["g_ns_lights"] = ragged(
+        [[lidx[id(tl)] for tl in g.opposite_pairs["N-S"]] for g in groups], 1)
+    out["g_ew_lights_off"], out["g_ew_lights"] = ragged(
+        [[lidx[id(tl)] for tl in g.opposite_pairs["W-E"]] for g in groups], 1)
+    nb = np.full((len(groups), 4, 2), -1, dtype=np.int32)
+    for i, g in enumerate(groups):
+        for k, (d, ng) in enumerate((g.neighbor_groups or {}).items()):
+            nb[i, k] = (DIRI[d], gidx.get(id(ng), -1))
+    out["g_neighbors"] = nb
+    for g, (a, b, c) in zip(groups, saved):
+        g.neighbor_groups, g.intermediate_groups, g.opposite_pairs = a, b, c
+    out["g_icell_off"], out["g_icell_xy"] = ragged(
+        [[c for cell in g.intersection_cells for c in cell.position] for g in groups], 2)
+    for nm in ("ns_in", "ns_out", "ew_in", "ew_out"):
+        out[f"g_{nm}_off"], out[f"g_{nm}_xy"] = ragged(
+            [[int(c) for xy in np.asarray(getattr(g, nm + "_coords")).reshape(-1, 2) for c in xy]
+             for g in groups], 2)
+    # schedule layout in insertion order: 0 = light group, 1 = city block, 2 = rain manager,
+    # 3 = traffic generator, 4 = other
+    kinds = []
+    for a in m.schedule.agents:
+        if isinstance(a, IntersectionLightGroup):
+            kinds.append(0)
+        elif isinstance(a, CityBlock):
+            kinds.append(1)
+        elif type(a).__name__ == "RainManager":
+            kinds.append(2)
+        elif type(a).__name__ == "DynamicTrafficAgent":
+            kinds.append(3)
+        else:
+            kinds.append(4)
+    out["schedule_kinds0"] = np.asarray(kinds, dtype=np.int8)
+    out["block_entrances_xy"] = np.asarray([c.position for c in m.block_entrances], dtype=np.int32).reshape(-1, 2)
+    out["highway_entrances_xy"] = np.asarray([c.position for c in m.highway_entrances], dtype=np.int32).reshape(-1, 2)
+    out["highway_exits_xy"] = np.asarray([c.position for c in m.highway_exits], dtype=np.int32).reshape(-1, 2)
+    return out
+
+
+VEH_FIELDS = ["spawn_idx", "x", "y", "base_speed", "current_speed", "max_steps", "direction",
+              "stuck_ticks", "cooldown", "flags", "stranded_left", "steps_traveled",
+              "path_len", "path_crc", "overtake_dur", "detour_dur"]
+F_EARLY, F_STUCK, F_PARKED, F_COLL, F_MALF, F_OVER, F_DETOUR, F_BLOCKED, F_HASPREV = (1 << i for i in range(9))
+
+GRP_FIELDS = ["current_phase", "pending_phase", "queue_timer", "gap_timer", "last_arrival",
+              "fixed_time_timer", "ft_phase", "ns_pressure", "ew_pressure"]
+CNT_FIELDS = ["stuck", "collisions", "malfunctions", "overtaking", "in_stuck_detour", "parked",
+              "live_internal", "live_through", "count_completed_internal", "count_completed_through",
+              "total_distance_internal", "total_distance_through", "errored_internal", "errored_through"]
+
+
+def veh_row(v):
+    flags = 0
+    flags |= F_EARLY if v._early_exit else 0
+    flags |= F_STUCK if v.is_stuck else 0
+    flags |= F_PARKED if v.is_parked else 0
+    flags |= F_COLL if v.is_in_collision else 0
+    flags |= F_MALF if v.is_in_malfunction else 0
+    flags |= F_OVER if v.is_overtaking else 0
+    flags |= F_DETOUR if v.is_in_stuck_detour else 0
+    flags |= F_BLOCKED if v.blocked_by_vehicle else 0
+    flags |= F_HASPREV if (v.previous_pos is not None and tuple(v.previous_pos) == tuple(v.pos)) else 0
+    crc = _crc_path(v.path)
+    return [v._g_idx, int(v.pos[0]), int(v.pos[1]), int(v.base_speed), int(v.current_speed), int(v.max_steps),
+            DIRI[v.direction], int(v.stuck_ticks), int(v.path_retry_cooldown), flags,
+            int(getattr(v, "_stranded_ticks_remaining", 0)), int(v.steps_traveled),
+            len(v.path), crc - (1 << 32) if crc >= (1 << 31) else crc,
+            int(v.overtaking_duration), int(v.stuck_detour_duration)]
+
+
+def none_i(v):
+    return -1 if v is None else int(v)
+
+
+def run_scenario(name):
+    import numpy as np
+    spec = SCENARIOS[name]
+    _setup_paths()
+    import random
+    from Simulation.config import Defaults
+    Defaults.SAVE_TOTAL_RESULTS = False
+    Defaults.SAVE_INDIVIDUAL_RESULTS = False
+    for k, v in spec["defaults"].items():
+        assert hasattr(Defaults, k), k
+        setattr(Defaults, k, v)
+    seed = spec["seed"]
+    random.seed(seed)
+    from Simulation.city_model import CityModel
+    from Simulation.agents.vehicles.vehicle_base import VehicleAgent
+    import Simulation.agents.vehicles.vehicle_base as vb
+
+    size = spec["size"]
+    m = CityModel(width=size, height=size, seed=seed, **spec.get("model_kwargs", {}))
+    out = world_tables(m)
+    out["scenario"] = np.asarray(json.dumps(dict(name=name, **{k: v for k, v in spec.items()})))
+    out["defaults_json"] = np.asarray(json.dumps(spec["defaults"]))
+
+    # numba float64 semantics for the soft penalty: density_map must be float64 when A* reads it
+    orig_update = CityModel._update_density_map
+
+    def upd(self):
+        orig_update(self)
+        self.density_map32 = self.density_map.astype(np.float32)
+        self.density_map = self.density_map.astype(np.float64)
+    CityModel._update_density_map = upd
+
+    # count A* calls
+    calls = {"n": 0}
+    orig_astar = vb.astar
+
+    def counting_astar(*a, **k):
+        calls["n"] += 1
+        return orig_astar(*a, **k)
+    vb.astar = counting_astar
+
+    m._update_density_map()
+
+    # ---- vehicles: distinct non-intersection road starts, exit-block goals ----
+    prng = random.Random(seed + 1)
+    road_cells = [(x, y) for y in range(m.height) for x in range(m.width)
+                  if m.is_road_map[y, x] == 1 and m.intersection_map[y, x] == 0]
+    nveh = min(spec["vehicles"], len(road_cells))
+    starts = prng.sample(road_cells, nveh)
+    exits = m.get_exit_blocks()
+    st_after_world = random.getstate()
+    out["global_rng_after_worldgen"] = np.asarray(st_after_world[1], dtype=np.uint32)
+    out["sched_rng_initial"] = np.asarray(m.random.getstate()[1], dtype=np.uint32)
+    v_start, v_goal, v_path_off, v_path_flat = [], [], [0], []
+    vehicles = []
+    for i, (sx, sy) in enumerate(starts):
+        goal = prng.choice(exits)
+        start_cell = m.get_cell_contents(sx, sy)[0]
+        v = VehicleAgent(f"gv_{i}", m, start_cell, goal, population_type="through")
+        v._g_idx = i
+        vehicles.append(v)
+        v_start.append((sx, sy))
+        v_goal.append(goal.get_position())
+        for p in v.path:
+            v_path_flat.append((int(p[0]), int(p[1])))
+        v_path_off.append(len(v_path_flat))
+    out["v_start_xy"] = np.asarray(v_start, dtype=np.int32).reshape(-1, 2)
+    out["v_goal_xy"] = np.asarray(v_goal, dtype=np.int32).reshape(-1, 2)
+    out["v_path0_off"] = np.asarray(v_path_off, dtype=np.int32)
+    out["v_path0_xy"] = np.asarray(v_path_flat, dtype=np.int32).reshape(-1, 2)
+    out["astar_calls_spawn"] = np.int32(calls["n"])
+    out["global_rng_after_spawn"] = np.asarray(random.getstate()[1], dtype=np.uint32)
+    out["occupancy0"] = m.occupancy_map.copy()
+
+    # vehicles spawned later by the traffic generator get indices >= nveh in creation order
+    counter = {"n": nveh}
+    orig_init = VehicleAgent.__init__
+
+    def init(self, *a, **k):
+        if not hasattr(self, "_g_idx"):
+            self._g_idx = counter["n"]
+            counter["n"] += 1
+        orig_init(self, *a, **k)
+    VehicleAgent.__init__ = init
+
+    T = spec["ticks"]
+    occ_t, stop_t, stuck_t = [], [], []
+    veh_rows, veh_off = [], [0]
+    grp_rows = []
+    cnt_rows = []
+    rng_rows = []
+    astar_per_tick = []
+    nsched = []
+    dta = getattr(m, "dynamic_traffic_generator", None)
+    dens_ticks = {}
+    for t in range(T):
+        c0 = calls["n"]
+        m.step()
+        astar_per_tick.append(calls["n"] - c0)
+        occ_t.append(np.packbits(m.occupancy_map.astype(np.uint8).ravel()))
+        stop_t.append(np.packbits(m.stop_map.astype(np.uint8).ravel()))
+        stuck_t.append(np.packbits(m.stuck_map.astype(np.uint8).ravel()))
+        for v in m.active_vehicle_agents:
+            veh_rows.append(veh_row(v))
+        veh_off.append(len(veh_rows))
+        grp_rows.append([[none_i(g.current_phase), none_i(g.pending_phase), g.queue_timer, g.gap_timer,
+                          g.last_arrival, g.fixed_time_timer, g._ft_phase, int(g.ns_pressure), int(g.ew_pressure)]
+                         for g in m.intersection_light_groups])
+        cnt_rows.append([int(getattr(dta, f, 0)) if dta is not None else 0 for f in CNT_FIELDS])
+        g_fp = _rng_fp(random.getstate())
+        s_fp = _rng_fp(m.random.getstate())
+        rng_rows.append([g_fp[0], g_fp[1], s_fp[0], s_fp[1]])
+        nsched.append(len(m.schedule._agents))
+        if t in (0, T // 2):
+            dens_ticks[t] = m.density_map32.copy()
+    out["occ_t"] = np.stack(occ_t)
+    out["stop_t"] = np.stack(stop_t)
+    out["stuck_t"] = np.stack(stuck_t)
+    out["veh_rows"] = np.asarray(veh_rows, dtype=np.int64).reshape(-1, len(VEH_FIELDS)).astype(np.int32)
+    out["veh_off"] = np.asarray(veh_off, dtype=np.int32)
+    out["grp_rows"] = np.asarray(grp_rows, dtype=np.int32).reshape(T, len(m.intersection_light_groups), len(GRP_FIELDS))
+    out["cnt_rows"] = np.asarray(cnt_rows, dtype=np.int64)
+    out["rng_rows"] = np.asarray(rng_rows, dtype=np.int64)
+    out["astar_per_tick"] = np.asarray(astar_per_tick, dtype=np.int32)
+    out["nsched_t"] = np.asarray(nsched, dtype=np.int32)
+    for t, d in dens_ticks.items():
+        out[f"density_t{t}"] = d
+    out["veh_fields"] = np.asarray(json.dumps(VEH_FIELDS))
+    out["grp_fields"] = np.asarray(json.dumps(GRP_FIELDS))
+    out["cnt_fields"] = np.asarray(json.dumps(CNT_FIELDS))
+    np.savez_compressed(os.path.join(HERE, f"trace_{name}.npz"), **out)
+    print(f"[{name}] groups={len(m.intersection_light_groups)} vehicles={nveh} ticks={T} "
+          f"astar/tick={np.mean(astar_per_tick):.2f} live_end={len(m.active_vehicle_agents)} "
+          f"size={os.path.getsize(os.path.join(HERE, f'trace_{name}.npz'))}")
+
+
+# --------------------------------------------------------------------------------------
+# G2: A* KATs, G3: density, G4: MT streams
+# --------------------------------------------------------------------------------------
+def run_astar_kats():
+    import numpy as np
+    _setup_paths()
+    import random
+    from Simulation.config import Defaults
+    Defaults.SAVE_TOTAL_RESULTS = False
+    Defaults.SAVE_INDIVIDUAL_RESULTS = False
+    for k, v in CLOSED.items():
+        setattr(Defaults, k, v)
+    random.seed(21)
+    from Simulation.city_model import CityModel
+    from Simulation.utilities.pathfinding.astar_numba import astar_numba
+    out = {}
+    for tag, size, seed, kw in (("a", 64, 21, {}), ("b", 80, 22, dict(carve_subblock_roads=True))):
+        random.seed(seed)
+        m = CityModel(width=size, height=size, seed=seed, **kw)
+        prng = random.Random(seed * 7)
+        road = [(x, y) for y in range(size) for x in range(size) if m.is_road_map[y, x] == 1]
+        # random dynamic state: occupancy on ~12% of road cells, red on ~half of the lights
+        for (x, y) in prng.sample(road, len(road) // 8):
+            m.occupancy_map[y, x] = 1
+        for tl in m.traffic_lights:
+            if prng.random() < 0.5:
+                tl.set_light_stop()
+        m._update_density_map()
+        dens64 = m.density_map.astype(np.float64)
+        queries, paths, poff = [], [], [0]
+        nq = 260
+        for q in range(nq):
+            (sx, sy), (gx, gy) = prng.choice(road), prng.choice(road)
+            mode = q % 4
+            soft, ign = bool(mode & 1), bool(mode & 2)
+            maxs = 0x7FFFFFFF
+            if ign:
+                maxs = prng.choice([6, 20, 0x7FFFFFFF])
+                if maxs != 0x7FFFFFFF:      # bounded searches: pick a nearby goal
+                    cands = [(x, y) for (x, y) in road if 0 < abs(x - sx) + abs(y - sy) <= 8]
+                    if cands:
+                        gx, gy = prng.choice(cands)
+            p = astar_numba(size, size, sx, sy, gx, gy, m.occupancy_map, m.stop_map, m.is_road_map,
+                            m.road_type_map, m.allowed_dirs_map, respect_awareness=False, awareness_range=10,
+                            density_map=dens64, soft_obstacles=soft, ignore_flow=ign, maximum_steps=maxs)
+            queries.append([sx, sy, gx, gy, int(soft), int(ign), maxs])
+            for c in p:
+                paths.append((int(c[0]), int(c[1])))
+            poff.append(len(paths))
+        wt = world_tables(m)
+        for k in ("allowed_dirs_map", "is_road_map", "road_type_map", "intersection_map"):
+            out[f"{tag}_{k}"] = wt[k]
+        out[f"{tag}_occupancy_map"] = m.occupancy_map.copy()
+        out[f"{tag}_stop_map"] = m.stop_map.copy()
+        out[f"{tag}_density32"] = m.density_map.astype(np.float32)
+        out[f"{tag}_queries"] = np.asarray(queries, dtype=np.int64)
+        out[f"{tag}_path_off"] = np.asarray(poff, dtype=np.int32)
+        out[f"{tag}_path_xy"] = np.asarray(paths, dtype=np.int32).reshape(-1, 2)
+        nonempty = sum(1 for i in range(nq) if poff[i + 1] > poff[i])
+        print(f"[astar_kats/{tag}] {nq} queries, {nonempty} non-empty")
+    np.savez_compressed(os.path.join(HERE, "astar_kats.npz"), **out)
+
+
+def run_density():
+    import numpy as np
+    from scipy.ndimage import uniform_filter
+    rng = np.random.RandomState(5)
+    out = {}
+    for tag, (h, w) in (("a", (64, 64)), ("b", (50, 97)), ("c", (21, 21)), ("d", (8, 40))):
+        road = (rng.rand(h, w) < 0.3).astype(np.int8)
+        occ = ((rng.rand(h, w) < 0.35) & (road == 1)).astype(np.int8)
+        if tag == "c":
+            occ = road.copy()
+        r = 10
+        o = occ.astype(np.float32)
+        so = uniform_filter(o, size=(2 * r + 1, 2 * r + 1), mode="constant", cval=0.0) * ((2 * r + 1) ** 2)
+        rd = road.astype(np.float32)
+        sr = uniform_filter(rd, size=(2 * r + 1, 2 * r + 1), mode="constant", cval=0.0) * ((2 * r + 1) ** 2)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d = np.where(sr > 0, so / sr, 0.0)
+        assert d.dtype == np.float32, d.dtype
+        out[f"{tag}_road"] = road
+        out[f"{tag}_occ"] = occ
+        out[f"{tag}_density"] = d
+    np.savez_compressed(os.path.join(HERE, "density_kats.npz"), **out)
+    print("[density] ok")
+
+
+def run_mt():
+    import random
+    import numpy as np
+    out = {}
+    for s in (0, 1, 12345, 2 ** 31 + 7, 2 ** 40 + 3):
+        r = random.Random(s)
+        out[f"s{s}_state0"] = np.asarray(r.getstate()[1], dtype=np.uint32)
+        out[f"s{s}_random"] = np.asarray([r.random() for _ in range(700)], dtype=np.float64)
+        out[f"s{s}_randint15"] = np.asarray([r.randint(1, 5) for _ in range(700)], dtype=np.int32)
+        out[f"s{s}_state_mid"] = np.asarray(r.getstate()[1], dtype=np.uint32)
+        for n in (1, 2, 13, 1000, 4099):
+            x = list(range(n))
+            r.shuffle(x)
+            out[f"s{s}_shuffle{n}"] = np.asarray(x, dtype=np.int32)
+        out[f"s{s}_randint09999"] = np.asarray([r.randint(0, 9999) for _ in range(100)], dtype=np.int32)
+        out[f"s{s}_state_end"] = np.asarray(r.getstate()[1], dtype=np.uint32)
+    out["seeds"] = np.asarray([0, 1, 12345, 2 ** 31 + 7, 2 ** 40 + 3], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "mt_kats.npz"), **out)
+    print("[mt] ok")
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "all":
+        jobs = ["mt", "density", "astar_kats"] + list(SCENARIOS)
+        for j in jobs:
+            subprocess.run([sys.executable, os.path.abspath(__file__), j], check=True, cwd="/tmp")
+        return
+    if what == "mt":
+        run_mt()
+    elif what == "density":
+        run_density()
+    elif what == "astar_kats":
+        run_astar_kats()
+    else:
+        run_scenario(what)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,346 @@
+"""ctypes binding of the C-ABI declared in include/trafficsim.h.
+
+`CApi(lib, prefix)` wraps one shared library exporting `<prefix>create`, `<prefix>step`, ...
+The product uses `prefix="ts_"` with trafficsimulation_amd/csrc/libtrafficsim_hip.so (see
+`_lib.py`); tests additionally instantiate it over the CPU oracle (`tso_`, oracle/libtso.so) so
+that both sides of a parity check are driven through identical host code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import zlib
+from typing import Optional, Sequence
+
+import numpy as np
+
+# ---- enums (mirror include/trafficsim.h) ----------------------------------------------------
+TS_OK, TS_E_INVALID, TS_E_STATE, TS_E_DEVICE, TS_E_UNSUPPORTED, TS_E_CAPACITY = 0, -1, -2, -3, -4, -5
+LIGHT_ALGORITHMS = {
+    "DISABLED": 0, "FIXED_TIME": 1, "QUEUE_ACTUATED": 2, "PRESSURE_CONTROL": 3,
+    "NEIGHBOR_PRESSURE_CONTROL": 4, "NEIGHBOR_GREEN_WAVE": 5,
+}
+AGENT_LIGHT_GROUP, AGENT_NOOP, AGENT_CLOCK = 0, 1, 3
+MAP_OCCUPANCY, MAP_STOP, MAP_STUCK, MAP_RAIN = 0, 1, 2, 3
+RNG_GLOBAL, RNG_SCHEDULER = 0, 1
+POP = {"undefined": 0, "internal": 1, "through": 2}
+V_FIELDS = ["spawn_idx", "x", "y", "base_speed", "current_speed", "max_steps", "direction", "stuck_ticks",
+            "cooldown", "flags", "stranded_left", "steps_traveled", "path_len", "path_crc", "overtake_dur",
+            "detour_dur"]
+G_FIELDS = ["current_phase", "pending_phase", "queue_timer", "gap_timer", "last_arrival", "fixed_time_timer",
+            "ft_phase", "ns_pressure", "ew_pressure"]
+F_EARLY_EXIT, F_STUCK, F_PARKED, F_COLLISION, F_MALFUNCTION, F_OVERTAKING, F_DETOUR, F_BLOCKED, F_HAS_PREV = (
+    1 << i for i in range(9))
+
+
+class TsParams(C.Structure):
+    _fields_ = [
+        ("vehicle_min_speed", C.c_int32), ("vehicle_max_speed", C.c_int32),
+        ("vehicle_awareness_range", C.c_int32), ("rain_enabled", C.c_int32),
+        ("rain_speed_reduction", C.c_int32), ("pathfinding_cooldown", C.c_int32),
+        ("pathfinding_cache", C.c_int32), ("stuck_recompute_threshold", C.c_int32),
+        ("stuck_recompute_threshold_intersection", C.c_int32), ("contraflow_overtake_active", C.c_int32),
+        ("max_contraflow_overtake_steps", C.c_int32), ("contraflow_overtake_duration", C.c_int32),
+        ("stuck_contraflow_enabled", C.c_int32), ("stuck_contraflow_threshold", C.c_int32),
+        ("stuck_contraflow_threshold_intersection", C.c_int32), ("max_contraflow_stuck_detour_steps", C.c_int32),
+        ("contraflow_stuck_detour_duration", C.c_int32), ("malfunction_active", C.c_int32),
+        ("malfunction_duration", C.c_int32), ("sideswipe_active", C.c_int32), ("sideswipe_duration", C.c_int32),
+        ("malfunction_chance", C.c_double), ("sideswipe_chance", C.c_double),
+        ("contraflow_penalty", C.c_int32), ("obstacle_penalty_vehicle", C.c_int32),
+        ("obstacle_penalty_stop", C.c_int32), ("road_type_penalties_enabled", C.c_int32),
+        ("turn_penalty_enabled", C.c_int32), ("turn_penalty", C.c_int32),
+        ("dynamic_penalties_enabled", C.c_int32), ("_pad0", C.c_int32),
+        ("road_type_penalty_r1", C.c_double), ("road_type_penalty_r2", C.c_double),
+        ("road_type_penalty_r3", C.c_double), ("dynamic_penalty_scale", C.c_double),
+        ("light_algorithm", C.c_int32), ("transition_duration_enabled", C.c_int32),
+        ("transition_clearance_enabled", C.c_int32), ("all_red_duration", C.c_int32),
+        ("green_duration", C.c_int32), ("qa_min_green", C.c_int32), ("qa_max_green", C.c_int32),
+        ("qa_gap", C.c_int32), ("enable_traffic", C.c_int32), ("time_per_step_seconds", C.c_int32),
+        ("eager_density", C.c_int32), ("_pad1", C.c_int32),
+    ]
+
+
+class TsWorld(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("allowed_dirs_map", C.c_void_p),
+                ("is_road_map", C.c_void_p), ("road_type_map", C.c_void_p), ("intersection_map", C.c_void_p)]
+
+
+_LT_PTRS = ["g_light_off", "light_xy", "light_ctrl_off", "light_ctrl_xy", "g_ns_off", "g_ns", "g_ew_off", "g_ew",
+            "g_icell_off", "g_icell_xy", "g_ns_in_off", "g_ns_in_xy", "g_ns_out_off", "g_ns_out_xy",
+            "g_ew_in_off", "g_ew_in_xy", "g_ew_out_off", "g_ew_out_xy", "g_neighbors", "g_neighbors_ctor"]
+
+
+class TsLightTables(C.Structure):
+    _fields_ = [("n_groups", C.c_int32), ("n_lights", C.c_int32)] + [(n, C.c_void_p) for n in _LT_PTRS]
+
+
+class TsCounters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "stuck", "collisions", "malfunctions", "overtaking", "in_stuck_detour", "parked", "live_internal",
+        "live_through", "count_completed_internal", "count_completed_through", "total_distance_internal",
+        "total_distance_through", "errored_internal", "errored_through")] + [
+        ("total_duration_internal", C.c_double), ("total_duration_through", C.c_double), ("elapsed", C.c_double)] + [
+        (n, C.c_int64) for n in ("step_count", "agent_steps", "astar_calls", "astar_expansions",
+                                 "astar_relaxations", "move_rounds", "rng_fixups")]
+
+
+# Defaults attribute name -> TsParams field (config.py)
+DEFAULTS_TO_PARAMS = {
+    "VEHICLE_MIN_SPEED": "vehicle_min_speed", "VEHICLE_MAX_SPEED": "vehicle_max_speed",
+    "VEHICLE_AWARENESS_RANGE": "vehicle_awareness_range", "RAIN_ENABLED": "rain_enabled",
+    "RAIN_SPEED_REDUCTION": "rain_speed_reduction", "PATHFINDING_COOLDOWN": "pathfinding_cooldown",
+    "PATHFINDING_CACHE": "pathfinding_cache", "VEHICLE_STUCK_RECOMPUTE_THRESHOLD": "stuck_recompute_threshold",
+    "VEHICLE_STUCK_RECOMPUTE_THRESHOLD_INTERSECTION": "stuck_recompute_threshold_intersection",
+    "VEHICLE_CONTRAFLOW_OVERTAKE_ACTIVE": "contraflow_overtake_active",
+    "VEHICLE_MAX_CONTRAFLOW_OVERTAKE_STEPS": "max_contraflow_overtake_steps",
+    "VEHICLE_CONTRAFLOW_OVERTAKE_DURATION": "contraflow_overtake_duration",
+    "VEHICLE_STUCK_CONTRAFLOW_ENABLED": "stuck_contraflow_enabled",
+    "VEHICLE_STUCK_CONTRAFLOW_THRESHOLD": "stuck_contraflow_threshold",
+    "VEHICLE_STUCK_CONTRAFLOW_THRESHOLD_INTERSECTION": "stuck_contraflow_threshold_intersection",
+    "VEHICLE_MAX_CONTRAFLOW_STUCK_DETOUR_STEPS": "max_contraflow_stuck_detour_steps",
+    "VEHICLE_CONTRAFLOW_STUCK_DETOUR_DURATION": "contraflow_stuck_detour_duration",
+    "VEHICLE_MALFUNCTION_ACTIVE": "malfunction_active", "VEHICLE_MALFUNCTION_CHANCE": "malfunction_chance",
+    "VEHICLE_MALFUNCTION_DURATION": "malfunction_duration",
+    "VEHICLE_SIDESWIPE_COLLISION_ACTIVE": "sideswipe_active",
+    "VEHICLE_SIDESWIPE_COLLISION_CHANCE": "sideswipe_chance",
+    "VEHICLE_SIDESWIPE_COLLISION_DURATION": "sideswipe_duration",
+    "VEHICLE_CONTRAFLOW_PENALTY": "contraflow_penalty",
+    "VEHICLE_OBSTACLE_PENALTY_VEHICLE": "obstacle_penalty_vehicle",
+    "VEHICLE_OBSTACLE_PENALTY_STOP": "obstacle_penalty_stop",
+    "VEHICLE_ROAD_TYPES_PENALTIES_ENABLED": "road_type_penalties_enabled",
+    "VEHICLE_ROAD_TYPES_PENALTY_R1": "road_type_penalty_r1", "VEHICLE_ROAD_TYPES_PENALTY_R2": "road_type_penalty_r2",
+    "VEHICLE_ROAD_TYPES_PENALTY_R3": "road_type_penalty_r3",
+    "VEHICLE_TURN_PENALTY_ENABLED": "turn_penalty_enabled", "VEHICLE_TURN_PENALTY": "turn_penalty",
+    "VEHICLE_DYNAMIC_PENALTIES_ENABLED": "dynamic_penalties_enabled",
+    "VEHICLE_DYNAMIC_PENALTY_SCALE": "dynamic_penalty_scale",
+    "TRAFFIC_LIGHT_AGENT_ALGORITHM": "light_algorithm",
+    "TRAFFIC_LIGHT_TRANSITION_DURATION_ENABLED": "transition_duration_enabled",
+    "TRAFFIC_LIGHT_TRANSITION_CLEARANCE_ENABLED": "transition_clearance_enabled",
+    "TRAFFIC_LIGHT_ALL_RED_DURATION": "all_red_duration", "TRAFFIC_LIGHT_GREEN_DURATION": "green_duration",
+    "TRAFFIC_LIGHT_QUEUE_ACTUATED_MIN_GREEN": "qa_min_green",
+    "TRAFFIC_LIGHT_QUEUE_ACTUATED_MAX_GREEN": "qa_max_green", "TRAFFIC_LIGHT_QUEUE_ACTUATED_GAP": "qa_gap",
+    "ENABLE_TRAFFIC": "enable_traffic", "TIME_PER_STEP_IN_SECONDS": "time_per_step_seconds",
+}
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"trafficsim error {code}: {msg}")
+        self.code = code
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def path_crc(xy) -> int:
+    """crc32 of a path as int32 (x, y) pairs, 0 if empty - the TS_V_PATH_CRC convention."""
+    a = _i32(xy).reshape(-1, 2)
+    if a.size == 0:
+        return 0
+    return zlib.crc32(a.tobytes()) & 0xFFFFFFFF
+
+
+class CApi:
+    """One engine instance behind the C-ABI (`prefix` = "ts_" for the HIP engine)."""
+
+    def __init__(self, lib: C.CDLL, prefix: str):
+        self.lib, self.prefix = lib, prefix
+        self.h = C.c_void_p()
+        self._keep = []
+        f = self._f
+        f("default_params").restype = None
+        f("last_error").restype = C.c_char_p
+        f("last_error").argtypes = [C.c_void_p]
+        for name in ("destroy", "num_vehicles", "num_groups", "num_scheduled"):
+            f(name).argtypes = [C.c_void_p]
+        f("create").argtypes = [C.POINTER(TsWorld), C.POINTER(TsParams), C.POINTER(C.c_void_p)]
+        f("set_lights").argtypes = [C.c_void_p, C.POINTER(TsLightTables)]
+        f("schedule_add").argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        f("seed").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32]
+        f("seed_int").argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
+        f("rng_state").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_uint32)]
+        f("add_vehicles").argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
+        f("upload_map").argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        f("step").argtypes = [C.c_void_p, C.c_int32]
+        f("download_map").argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        f("download_density").argtypes = [C.c_void_p, C.c_void_p]
+        f("download_vehicles").argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        f("download_path").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        f("download_groups").argtypes = [C.c_void_p, C.c_void_p]
+        f("counters").argtypes = [C.c_void_p, C.POINTER(TsCounters)]
+        f("astar").argtypes = [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p, C.c_int32]
+        f("debug_set_occupancy").argtypes = [C.c_void_p, C.c_void_p]
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def _chk(self, rc: int) -> int:
+        if rc < 0:
+            msg = self._f("last_error")(self.h) if self.h else b""
+            raise EngineError(rc, (msg or b"").decode())
+        return rc
+
+    # ---- construction ----------------------------------------------------------------------
+    def default_params(self) -> TsParams:
+        p = TsParams()
+        self._f("default_params")(C.byref(p))
+        return p
+
+    def params_from_defaults(self, overrides: Optional[dict] = None) -> TsParams:
+        """TsParams from config.py defaults plus `Defaults`-style overrides (UPPER_CASE keys)."""
+        p = self.default_params()
+        for k, v in (overrides or {}).items():
+            if k in DEFAULTS_TO_PARAMS:
+                field = DEFAULTS_TO_PARAMS[k]
+                if field == "light_algorithm":
+                    if v not in LIGHT_ALGORITHMS:
+                        raise EngineError(TS_E_UNSUPPORTED, f"light algorithm {v!r} is out of scope (RL variants)")
+                    v = LIGHT_ALGORITHMS[v]
+                setattr(p, field, type(getattr(p, field))(v))
+        return p
+
+    def create(self, allowed_dirs, is_road, road_type, intersection, params: TsParams):
+        a = np.ascontiguousarray(allowed_dirs, dtype=np.uint8)
+        r = np.ascontiguousarray(is_road, dtype=np.int8)
+        t = np.ascontiguousarray(road_type, dtype=np.int8)
+        i = np.ascontiguousarray(intersection, dtype=np.int8)
+        H, W = a.shape
+        assert r.shape == t.shape == i.shape == (H, W)
+        self.W, self.H = W, H
+        w = TsWorld(W, H, a.ctypes.data, r.ctypes.data, t.ctypes.data, i.ctypes.data)
+        rc = self._f("create")(C.byref(w), C.byref(params), C.byref(self.h))
+        if rc < 0:
+            raise EngineError(rc, "create failed")
+        return self
+
+    def close(self):
+        if self.h:
+            self._f("destroy")(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_lights(self, tables: dict):
+        """`tables`: the G1 light tables (keys as in tests/golden world tables / citygen)."""
+        t = TsLightTables()
+        arrs = {
+            "g_light_off": tables["g_light_off"], "light_xy": tables["light_xy"],
+            "light_ctrl_off": tables["light_ctrl_off"], "light_ctrl_xy": tables["light_ctrl_xy"],
+            "g_ns_off": tables["g_ns_lights_off"], "g_ns": tables["g_ns_lights"],
+            "g_ew_off": tables["g_ew_lights_off"], "g_ew": tables["g_ew_lights"],
+            "g_icell_off": tables["g_icell_off"], "g_icell_xy": tables["g_icell_xy"],
+            "g_ns_in_off": tables["g_ns_in_off"], "g_ns_in_xy": tables["g_ns_in_xy"],
+            "g_ns_out_off": tables["g_ns_out_off"], "g_ns_out_xy": tables["g_ns_out_xy"],
+            "g_ew_in_off": tables["g_ew_in_off"], "g_ew_in_xy": tables["g_ew_in_xy"],
+            "g_ew_out_off": tables["g_ew_out_off"], "g_ew_out_xy": tables["g_ew_out_xy"],
+            "g_neighbors": tables["g_neighbors"],
+            "g_neighbors_ctor": tables.get("g_neighbors_ctor", tables["g_neighbors"]),
+        }
+        keep = {k: _i32(v) for k, v in arrs.items()}
+        t.n_groups = len(keep["g_light_off"]) - 1
+        t.n_lights = len(keep["light_ctrl_off"]) - 1
+        for k, v in keep.items():
+            setattr(t, k, v.ctypes.data)
+        self._chk(self._f("set_lights")(self.h, C.byref(t)))
+        self.n_groups = t.n_groups
+
+    def schedule_add(self, kind: int, count: int = 1):
+        self._chk(self._f("schedule_add")(self.h, kind, count))
+
+    def seed_state(self, stream: int, state):
+        """`state` = random.getstate() (or just its [1] tuple of 625 ints)."""
+        tup = state[1] if (isinstance(state, tuple) and len(state) == 3) else state
+        arr = np.asarray(tup, dtype=np.uint64)
+        assert arr.size == 625
+        mt = np.ascontiguousarray(arr[:624].astype(np.uint32))
+        self._chk(self._f("seed")(self.h, stream, mt.ctypes.data, int(arr[624])))
+
+    def seed_int(self, stream: int, seed: int):
+        self._chk(self._f("seed_int")(self.h, stream, seed))
+
+    def rng_state(self, stream: int):
+        mt = np.zeros(624, dtype=np.uint32)
+        idx = C.c_uint32()
+        self._chk(self._f("rng_state")(self.h, stream, mt.ctypes.data, C.byref(idx)))
+        return mt, idx.value
+
+    def rng_fingerprint(self, stream: int):
+        mt, idx = self.rng_state(stream)
+        return zlib.crc32(mt.tobytes()) & 0xFFFFFFFF, idx
+
+    def add_vehicles(self, start_xy, goal_xy, population_type=None, path_off=None, path_xy=None):
+        s, g = _i32(start_xy).reshape(-1, 2), _i32(goal_xy).reshape(-1, 2)
+        n = len(s)
+        pt = _i32(population_type if population_type is not None else np.zeros(n))
+        po = px = None
+        if path_off is not None:
+            po, px = _i32(path_off), _i32(path_xy).reshape(-1, 2)
+            assert len(po) == n + 1
+        self._chk(self._f("add_vehicles")(
+            self.h, n, s.ctypes.data, g.ctypes.data, pt.ctypes.data,
+            po.ctypes.data if po is not None else None, px.ctypes.data if px is not None else None))
+
+    def upload_map(self, which: int, arr):
+        a = np.ascontiguousarray(arr, dtype=np.int8)
+        assert a.shape == (self.H, self.W)
+        self._chk(self._f("upload_map")(self.h, which, a.ctypes.data))
+
+    def debug_set_occupancy(self, arr):
+        """Test hook: overwrite occupancy_map without placing vehicles (A*/density KATs)."""
+        a = np.ascontiguousarray(arr, dtype=np.int8)
+        assert a.shape == (self.H, self.W)
+        self._chk(self._f("debug_set_occupancy")(self.h, a.ctypes.data))
+
+    # ---- stepping and read-back ---------------------------------------------------------------
+    def step(self, n: int = 1):
+        self._chk(self._f("step")(self.h, n))
+
+    def num_vehicles(self) -> int:
+        return self._chk(self._f("num_vehicles")(self.h))
+
+    def num_scheduled(self) -> int:
+        return self._chk(self._f("num_scheduled")(self.h))
+
+    def map(self, which: int) -> np.ndarray:
+        out = np.zeros((self.H, self.W), dtype=np.int8)
+        self._chk(self._f("download_map")(self.h, which, out.ctypes.data))
+        return out
+
+    def density(self) -> np.ndarray:
+        out = np.zeros((self.H, self.W), dtype=np.float32)
+        self._chk(self._f("download_density")(self.h, out.ctypes.data))
+        return out
+
+    def vehicles(self) -> np.ndarray:
+        n = self.num_vehicles()
+        out = np.zeros((max(n, 1), len(V_FIELDS)), dtype=np.int32)
+        got = self._chk(self._f("download_vehicles")(self.h, out.ctypes.data, max(n, 1)))
+        return out[:got]
+
+    def path(self, active_pos: int) -> np.ndarray:
+        n = self._chk(self._f("download_path")(self.h, active_pos, None, 0))
+        out = np.zeros((max(n, 1), 2), dtype=np.int32)
+        self._chk(self._f("download_path")(self.h, active_pos, out.ctypes.data, max(n, 1)))
+        return out[:n]
+
+    def groups(self) -> np.ndarray:
+        n = self._chk(self._f("num_groups")(self.h))
+        out = np.zeros((max(n, 1), len(G_FIELDS)), dtype=np.int32)
+        self._chk(self._f("download_groups")(self.h, out.ctypes.data))
+        return out[:n]
+
+    def counters(self) -> TsCounters:
+        c = TsCounters()
+        self._chk(self._f("counters")(self.h, C.byref(c)))
+        return c
+
+    def astar(self, sx, sy, gx, gy, soft_obstacles=False, ignore_flow=False, maximum_steps=0x7FFFFFFF):
+        cap = self.W * self.H
+        out = np.zeros((cap, 2), dtype=np.int32)
+        n = self._chk(self._f("astar")(self.h, sx, sy, gx, gy, int(soft_obstacles), int(ignore_flow),
+                                       int(maximum_steps), out.ctypes.data, cap))
+        return out[:n].copy()
