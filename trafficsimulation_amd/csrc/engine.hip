@@ -1,0 +1,1524 @@
+// engine.hip - MI355X-native per-timestep agent-update engine (gfx950), C-ABI of include/trafficsim.h.
+//
+// One tick = CityModel.step() (city_model.py:1831-1860):
+//   decide  : k_decide_pre  -> host MT19937 scan (data-dependent sequential stream) -> k_decide_main
+//   move    : host MT19937 shuffle (model.random) -> rank per scheduled agent ->
+//             rounds of { k_move_claim (per-cell min-rank claims) ; k_move_resolve } until every agent
+//             has stepped.  An agent executes in the round in which no lower-ranked unresolved agent
+//             touches a cell it reads or writes, which reproduces the sequential shuffled order exactly.
+//   compact : stable compaction of active_vehicle_agents / schedule after despawns.
+//
+// State lives in HBM as structure-of-arrays; maps are (H, W) byte planes.  All arithmetic is integer
+// except the float32 density map.  See DESIGN.md for the layout and the per-kernel byte counts.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/trafficsim.h"
+#include "mt19937.h"
+
+#define BLK 256
+
+namespace {
+
+// vehicle flag bits: TS_F_* (1..256) plus engine-private ones
+constexpr uint16_t VF_EARLY = TS_F_EARLY_EXIT, VF_STUCK = TS_F_STUCK, VF_PARKED = TS_F_PARKED,
+                   VF_COLL = TS_F_COLLISION, VF_MALF = TS_F_MALFUNCTION, VF_OVER = TS_F_OVERTAKING,
+                   VF_DETOUR = TS_F_DETOUR, VF_BLOCKED = TS_F_BLOCKED, VF_HASPREV = TS_F_HAS_PREV,
+                   VF_KEEP = 512 /* remove_on_arrival == False */, VF_ALIVE = 1024;
+constexpr int8_t K_VEHICLE = 100, K_DEAD = -1;
+constexpr uint32_t RANK_BITS = 22, RANK_MASK = (1u << RANK_BITS) - 1, EPOCHS = 1u << (32 - RANK_BITS);
+constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
+
+// decide-phase flag byte F (k_decide_pre -> host scan)
+constexpr uint8_t F_DRAW_MALF = 1, F_DRAW_SWIPE = 2, F_DRAW_SPEED = 4;
+
+struct DevCnt {
+  long long stuck, collisions, malfunctions, overtaking, in_stuck_detour, parked, live_internal, live_through,
+      completed_internal, completed_through, dist_internal, dist_through;
+  double dur_internal, dur_through;
+  int resolved;    // agents stepped so far in this move phase
+  int deaths;      // vehicles removed this tick
+  int need_astar;  // replans requested by k_decide_main (GPU A* not built yet -> TS_E_UNSUPPORTED)
+  int error;       // sticky device-side error
+};
+
+struct Dev {
+  int W, H, N;
+  int8_t *occ, *stop, *stuck, *rain;
+  uint8_t* allowed;
+  int8_t *is_road, *road_type, *inter;
+  // vehicles (indexed by vehicle id = spawn index)
+  int32_t *pos, *target, *path_len, *path_cur, *stuck_ticks, *cooldown, *stranded_left, *steps, *over_dur, *det_dur,
+      *next_in_cell, *active_idx, *sched_slot;
+  uint32_t* path_off;
+  int8_t *base_speed, *cur_speed, *max_steps, *dir, *pop;
+  uint16_t* flags;
+  double* depart;
+  uint8_t *ev, *st_before, *st_after;
+  uint32_t* pool;
+  int32_t* cell_veh;  // first vehicle in the cell's MultiGrid list, -1 = none
+  // ordered lists
+  int32_t* active;    // active_vehicle_agents (vehicle ids, -1 = removed this tick)
+  int8_t* sched_kind;
+  int32_t* sched_ref;
+  uint32_t* rank;     // per schedule slot
+  uint8_t* resolved;  // per schedule slot, this move phase
+  // light groups (CSR tables + state)
+  int G;
+  int32_t *g_light_off, *light_cell, *light_ctrl_off, *light_ctrl, *g_ns_off, *g_ns, *g_ew_off, *g_ew, *g_icell_off,
+      *g_icell, *g_nsin_off, *g_nsin, *g_nsout_off, *g_nsout, *g_ewin_off, *g_ewin, *g_ewout_off, *g_ewout, *g_nb,
+      *g_nb_ctor, *g_slot;
+  int32_t *gs_cur, *gs_pend, *gs_trans, *gs_clear, *gs_ftphase, *gs_fttimer, *gs_qtimer, *gs_gap, *gs_last, *gs_nsp,
+      *gs_ewp, *gs_repop;
+  // per-cell min-rank claims for the move phase (epoch-tagged so they never need clearing)
+  uint32_t *cw_occ, *cr_occ, *cw_stop, *cr_stop, *gclaim_r;
+  // decide-phase exchange buffers
+  uint8_t *F, *R;
+  int32_t* cand;
+  DevCnt* cnt;
+};
+
+__device__ __forceinline__ int path_dir(const uint32_t* pool, uint32_t off, int k) {
+  return (pool[off + ((uint32_t)k >> 4)] >> ((k & 15) * 2)) & 3;
+}
+__device__ __forceinline__ int step_cell(int cell, int dir, int W) {
+  return dir == 0 ? cell + W : dir == 1 ? cell + 1 : dir == 2 ? cell - W : cell - 1;
+}
+__device__ __forceinline__ uint32_t claim_rank(uint32_t v, uint32_t prefix) {
+  return (v >> RANK_BITS) == prefix ? (v & RANK_MASK) : NO_RANK;
+}
+
+// "is ag stranded, as vehicle number my_idx of the decide order sees it" - earlier vehicles have already
+// run their step_decide this tick (countdown applied, events visible), later ones have not.
+__device__ __forceinline__ bool seen_stranded(const Dev& d, int ag, int my_idx) {
+  if (d.active_idx[ag] < my_idx) return d.ev[ag] ? true : (d.st_after[ag] != 0);
+  return d.st_before[ag] != 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// decide, part 1 (pure): which draws of the global MT19937 stream does each vehicle consume?
+// step_decide prologue, vehicle_base.py:616-643 with _tick_stranded 552-565, _check_malfunction
+// 608-610, _check_sideswipe_collision 567-605, _is_at_stopped_cell 121-127, _compute_speed 94-107.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_decide_pre(Dev d, TsParams P, int start, int n_active) {
+  int i = start + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_active) return;
+  int vid = d.active[i];
+  if (vid < 0) { d.F[i] = 0; return; }
+  uint16_t f = d.flags[vid];
+  bool sb = (f & (VF_COLL | VF_MALF)) != 0;
+  bool sa = sb && (d.stranded_left[vid] - 1 > 0);
+  if (!P.malfunction_active) sa = true;  // `not ACTIVE or ...`: every vehicle malfunctions (vehicle_base.py:609)
+  d.st_before[vid] = sb;
+  d.st_after[vid] = sa;
+}
+__global__ void k_decide_pre2(Dev d, TsParams P, int start, int n_active) {
+  int i = start + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_active) return;
+  int vid = d.active[i];
+  uint8_t F = 0;
+  int cand = -1;
+  if (vid >= 0) {
+    uint16_t f = d.flags[vid];
+    bool sb = (f & (VF_COLL | VF_MALF)) != 0;
+    bool still = sb && (d.stranded_left[vid] - 1 > 0);
+    if (!still && P.malfunction_active) {
+      F |= F_DRAW_MALF;
+      const int W = d.W, H = d.H;
+      int pos = d.pos[vid];
+      int dir = d.dir[vid];
+      if (P.sideswipe_active && dir >= 0) {
+        int x = pos % W, y = pos / W;
+        const int opposite = (dir + 2) & 3;
+        for (int k = 0; k < 2 && cand < 0; k++) {
+          int ld = k == 0 ? ((dir + 3) & 3) : ((dir + 1) & 3);  // left, then right
+          int nx = x + (ld == 1) - (ld == 3), ny = y + (ld == 0) - (ld == 2);
+          if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
+          for (int ag = d.cell_veh[ny * W + nx]; ag >= 0; ag = d.next_in_cell[ag]) {
+            uint16_t af = d.flags[ag];
+            bool earlier = d.active_idx[ag] < i;
+            bool ag_str = earlier ? (d.ev[ag] ? true : d.st_after[ag] != 0) : (d.st_before[ag] != 0);
+            bool cs_pos = earlier ? (!ag_str && d.stop[d.pos[ag]] != 1) : (d.cur_speed[ag] > 0);
+            if (!cs_pos || (af & (VF_STUCK | VF_PARKED)) || ag_str) continue;
+            if (d.dir[ag] != opposite) continue;
+            cand = ag;
+            break;
+          }
+        }
+        if (cand >= 0) F |= F_DRAW_SWIPE;
+      }
+      if (d.stop[pos] != 1 && d.base_speed[vid] == 0) F |= F_DRAW_SPEED;
+    }
+  }
+  d.F[i] = F;
+  d.cand[i] = cand;
+}
+
+// _set_malfunction / _set_collision (vehicle_base.py:534-550) for the (rare) events the host scan finds.
+// ev: 1 = stranded at its own decide point (early exit there); 2 = hit by a later vehicle after deciding.
+__global__ void k_apply_event(Dev d, TsParams P, int vid, int is_collision, int partner, int my_idx) {
+  if (threadIdx.x || blockIdx.x) return;
+  if (!is_collision) {
+    d.flags[vid] = (d.flags[vid] | VF_MALF) & ~VF_COLL;
+    d.stranded_left[vid] = P.malfunction_duration;
+    d.base_speed[vid] = 0; d.cur_speed[vid] = 0;
+    d.ev[vid] = 1;
+    atomicAdd((unsigned long long*)&d.cnt->malfunctions, 1ULL);
+  } else {
+    d.flags[vid] = (d.flags[vid] | VF_COLL) & ~VF_MALF;
+    d.stranded_left[vid] = P.sideswipe_duration;
+    d.base_speed[vid] = 0; d.cur_speed[vid] = 0;
+    d.ev[vid] = 1;
+    d.flags[partner] = (d.flags[partner] | VF_COLL) & ~VF_MALF;
+    d.stranded_left[partner] = P.sideswipe_duration;
+    d.base_speed[partner] = 0; d.cur_speed[partner] = 0;
+    if (d.active_idx[partner] < my_idx) d.ev[partner] = 2;
+    atomicAdd((unsigned long long*)&d.cnt->collisions, 2ULL);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decide, part 2: step_decide body (vehicle_base.py:616-663) with _scan_ahead_for_obstacles 422-452,
+// _recompute_path_on_stuck 506-517, _recompute_path_on_obstacle 454-504 (replans are requested, not run,
+// until the GPU A* lands), _determine_max_steps 719-731.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_decide_main(Dev d, TsParams P, int n_active) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_active) return;
+  int vid = d.active[i];
+  if (vid < 0) return;
+  uint16_t f = d.flags[vid] & ~(VF_EARLY);
+  const uint8_t ev = d.ev[vid];
+  int base = d.base_speed[vid], cur = d.cur_speed[vid];
+  const int pos = d.pos[vid];
+  bool early = false;
+  if (ev == 1) {  // became stranded at its own decide point: state already written by k_apply_event
+    base = 0; cur = 0; early = true;
+  } else {
+    if (ev != 2 && (f & (VF_COLL | VF_MALF))) {  // _tick_stranded
+      int left = d.stranded_left[vid] - 1;
+      if (left <= 0) {
+        if (f & VF_COLL) atomicAdd((unsigned long long*)&d.cnt->collisions, (unsigned long long)-1LL);
+        if (f & VF_MALF) atomicAdd((unsigned long long*)&d.cnt->malfunctions, (unsigned long long)-1LL);
+        f &= ~(VF_COLL | VF_MALF);
+        left = 0;
+      }
+      d.stranded_left[vid] = left;
+      if (f & (VF_COLL | VF_MALF)) { base = 0; cur = 0; early = true; }
+    }
+    if (!early && !P.malfunction_active) {  // malfunction without a draw
+      f = (f | VF_MALF) & ~VF_COLL;
+      d.stranded_left[vid] = P.malfunction_duration;
+      atomicAdd((unsigned long long*)&d.cnt->malfunctions, 1ULL);
+      base = 0; cur = 0; early = true;
+    }
+    if (!early && d.stop[pos] == 1) { base = 0; cur = 0; early = true; }
+  }
+  if (!early) {
+    if (base == 0) base = d.R[i];  // _choose_new_speed: rolled by the host scan
+    int speed = base;
+    if (P.rain_enabled && d.rain[pos] == 1) speed = max(1, speed - P.rain_speed_reduction);
+    cur = speed;
+    bool need_astar = false;
+    // _recompute_path_on_stuck
+    int thresh = d.inter[pos] == 1 ? P.stuck_recompute_threshold_intersection : P.stuck_recompute_threshold;
+    if (d.stuck_ticks[vid] >= thresh) need_astar = true;
+    if (f & (VF_OVER | VF_DETOUR)) need_astar = true;  // contraflow state only arises from replans
+    // _scan_ahead_for_obstacles
+    const uint32_t off = d.path_off[vid];
+    const int pcur = d.path_cur[vid];
+    const int plen = d.path_len[vid] - pcur;
+    int idx_stop = -1, idx_veh = -1, first_cell = -1;
+    {
+      int look = min(P.vehicle_awareness_range, plen);
+      int c = pos;
+      for (int k = 0; k < look; k++) {
+        c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
+        if (k == 0) first_cell = c;
+        if (idx_stop < 0 && d.stop[c] == 1) idx_stop = k;
+        if (idx_veh < 0 && d.occ[c] == 1) idx_veh = k;
+        if (idx_stop == 0 || idx_veh == 0) break;
+      }
+    }
+    // _recompute_path_on_obstacle (cooldown gate; the replan itself needs A*)
+    if (!need_astar) {
+      int cd = d.cooldown[vid];
+      bool gate_open = true;
+      if (cd > 0) {
+        if (idx_veh == 0) {
+          int b = d.cell_veh[first_cell];
+          if (b >= 0 && (seen_stranded(d, b, i) || (d.flags[b] & VF_PARKED))) {
+            // immediate pathfinding
+          } else { d.cooldown[vid] = cd - 1; gate_open = false; }
+        } else { d.cooldown[vid] = cd - 1; gate_open = false; }
+      }
+      if (gate_open && (idx_stop >= 0 || idx_veh >= 0)) need_astar = true;
+    }
+    if (need_astar) atomicAdd(&d.cnt->need_astar, 1);
+    // _determine_max_steps
+    int ms = min(cur, plen);
+    bool blocked = false;
+    if (idx_stop >= 0) ms = min(ms, idx_stop);
+    if (idx_veh >= 0) { if (idx_veh == 0) blocked = true; ms = min(ms, idx_veh); }
+    d.max_steps[vid] = (int8_t)ms;
+    f = blocked ? (f | VF_BLOCKED) : (f & ~VF_BLOCKED);
+    if (ms <= 0) {
+      base = 0;
+      if (pos == d.target[vid]) atomicExch(&d.cnt->error, TS_E_UNSUPPORTED);  // despawn inside decide (start == goal)
+      early = true;
+    }
+  }
+  if (ev == 2) { base = 0; cur = 0; }  // collision inflicted after this vehicle had decided
+  d.base_speed[vid] = (int8_t)base;
+  d.cur_speed[vid] = (int8_t)cur;
+  d.flags[vid] = early ? (f | VF_EARLY) : f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// move phase
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void claim(uint32_t* arr, int cell, uint32_t key) { atomicMin(&arr[cell], key); }
+
+__device__ __forceinline__ bool group_reads_out(const TsParams& P) {
+  return P.light_algorithm == TS_LIGHTS_PRESSURE_CONTROL || P.light_algorithm == TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL;
+}
+__device__ __forceinline__ bool group_reads_neighbors(const TsParams& P) {
+  return P.light_algorithm == TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL || P.light_algorithm == TS_LIGHTS_NEIGHBOR_GREEN_WAVE;
+}
+
+// Every unresolved agent announces the cells it will read/write: cw_* = min rank of writers,
+// cr_* = min rank of readers.  Keys carry an epoch prefix that DEcreases every round, so atomicMin
+// makes stale entries of earlier rounds lose and nothing has to be cleared.
+__global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_sched || d.resolved[s]) return;
+  const int8_t kind = d.sched_kind[s];
+  const uint32_t key = (prefix << RANK_BITS) | d.rank[s];
+  if (kind == K_VEHICLE) {
+    const int vid = d.sched_ref[s];
+    const uint16_t f = d.flags[vid];
+    const int pos = d.pos[vid];
+    if (f & VF_EARLY) {
+      if (d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED) claim(d.cr_stop, pos, key);  // tick_stuck reads stop[pos]
+      if (pos == d.target[vid]) claim(d.cw_occ, pos, key);
+    } else {
+      const int m = d.max_steps[vid];
+      claim(d.cw_occ, pos, key);
+      const uint32_t off = d.path_off[vid];
+      const int pcur = d.path_cur[vid];
+      int c = pos;
+      for (int k = 0; k < m; k++) {
+        c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
+        claim(d.cw_occ, c, key);
+        if (d.G > 0) claim(d.cr_stop, c, key);
+      }
+    }
+  } else if (kind == TS_AGENT_LIGHT_GROUP && P.light_algorithm != TS_LIGHTS_DISABLED) {
+    const int g = d.sched_ref[s];
+    for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1]; k++) claim(d.cr_occ, d.g_icell[k], key);
+    for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1]; k++) claim(d.cr_occ, d.g_nsin[k], key);
+    for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1]; k++) claim(d.cr_occ, d.g_ewin[k], key);
+    if (group_reads_out(P)) {
+      for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1]; k++) claim(d.cr_occ, d.g_nsout[k], key);
+      for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1]; k++) claim(d.cr_occ, d.g_ewout[k], key);
+    }
+    for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1]; l++) {
+      claim(d.cw_stop, d.light_cell[l], key);
+      for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) claim(d.cw_stop, d.light_ctrl[k], key);
+    }
+    if (group_reads_neighbors(P)) {
+      for (int k = 0; k < 4; k++) {
+        int n1 = d.g_nb[(g * 4 + k) * 2 + 1], n2 = d.g_nb_ctor[(g * 4 + k) * 2 + 1];
+        if (n1 >= 0) atomicMin(&d.gclaim_r[n1], key);
+        if (n2 >= 0) atomicMin(&d.gclaim_r[n2], key);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void cell_unlink(const Dev& d, int cell, int vid) {
+  int h = d.cell_veh[cell];
+  if (h == vid) { d.cell_veh[cell] = d.next_in_cell[vid]; return; }
+  while (h >= 0 && d.next_in_cell[h] != vid) h = d.next_in_cell[h];
+  if (h >= 0) d.next_in_cell[h] = d.next_in_cell[vid];
+}
+__device__ __forceinline__ void cell_append(const Dev& d, int cell, int vid) {
+  d.next_in_cell[vid] = -1;
+  int h = d.cell_veh[cell];
+  if (h < 0) { d.cell_veh[cell] = vid; return; }
+  while (d.next_in_cell[h] >= 0) h = d.next_in_cell[h];
+  d.next_in_cell[h] = vid;
+}
+
+// on_target_reached (vehicle_base.py:755-775) -> _despawn -> CityModel.remove_vehicle (city_model.py:1920-1941)
+__device__ void on_target_reached_dev(const Dev& d, const TsParams& P, int vid, int s, int pos, uint16_t& f,
+                                      double elapsed_now) {
+  if (P.enable_traffic) {
+    double duration = elapsed_now - d.depart[vid];
+    int pop = d.pop[vid];
+    if (pop == TS_POP_INTERNAL) {
+      atomicAdd(&d.cnt->dur_internal, duration);
+      atomicAdd((unsigned long long*)&d.cnt->dist_internal, (unsigned long long)d.steps[vid]);
+      atomicAdd((unsigned long long*)&d.cnt->completed_internal, 1ULL);
+    } else if (pop == TS_POP_THROUGH) {
+      atomicAdd(&d.cnt->dur_through, duration);
+      atomicAdd((unsigned long long*)&d.cnt->dist_through, (unsigned long long)d.steps[vid]);
+      atomicAdd((unsigned long long*)&d.cnt->completed_through, 1ULL);
+    }
+  }
+  if (!(f & VF_KEEP)) {
+    d.occ[pos] = 0; d.stuck[pos] = 0;
+    cell_unlink(d, pos, vid);
+    f &= ~VF_ALIVE;
+    d.sched_kind[s] = K_DEAD;
+    d.active[d.active_idx[vid]] = -1;
+    int pop = d.pop[vid];
+    if (pop == TS_POP_INTERNAL) atomicAdd((unsigned long long*)&d.cnt->live_internal, (unsigned long long)-1LL);
+    else if (pop == TS_POP_THROUGH) atomicAdd((unsigned long long*)&d.cnt->live_through, (unsigned long long)-1LL);
+    atomicAdd(&d.cnt->deaths, 1);
+  } else if (!(f & VF_PARKED)) {
+    f |= VF_PARKED;
+    atomicAdd((unsigned long long*)&d.cnt->parked, 1ULL);
+  }
+}
+
+// VehicleAgent.step with PATHFINDING_BATCHING (vehicle_base.py:666-685): _execute_movement 733-753,
+// _move_to 521-532 + CityModel.move_vehicle (city_model.py:1945-1963), tick_stuck 687-693.
+__device__ void vehicle_step_dev(const Dev& d, const TsParams& P, int vid, int s, double elapsed_now) {
+  uint16_t f = d.flags[vid];
+  int pos = d.pos[vid];
+  if (!(f & VF_EARLY)) {
+    const int m = d.max_steps[vid];
+    const uint32_t off = d.path_off[vid];
+    const int pcur = d.path_cur[vid];
+    const int plen = d.path_len[vid] - pcur;
+    const bool was_stuck = (f & VF_STUCK) != 0;
+    int c = pos, moved = 0, lastdir = -1;
+    for (int k = 0; k < m; k++) {
+      if (k >= plen) break;
+      int nd = path_dir(d.pool, off, pcur + k);
+      int nc = step_cell(c, nd, d.W);
+      if (d.occ[nc] == 1) break;
+      if (d.stop[nc] == 1 && k != m - 1) break;
+      d.occ[c] = 0; d.occ[nc] = 1;
+      d.stuck[c] = 0; d.stuck[nc] = (k == 0 && was_stuck) ? 1 : 0;
+      c = nc; moved++; lastdir = nd;
+    }
+    if (moved) {
+      cell_unlink(d, pos, vid);
+      cell_append(d, c, vid);
+      pos = c;
+      d.pos[vid] = c;
+      d.dir[vid] = (int8_t)lastdir;
+      if (d.stuck_ticks[vid] > 0) {
+        if (was_stuck) { atomicAdd((unsigned long long*)&d.cnt->stuck, (unsigned long long)-1LL); f &= ~VF_STUCK; }
+        d.stuck_ticks[vid] = 0;
+      }
+      d.steps[vid] += moved;
+      d.path_cur[vid] = pcur + moved;
+    }
+    f |= VF_HASPREV;
+  } else {
+    f &= ~VF_EARLY;
+    if ((f & VF_HASPREV) && d.stop[pos] != 1) {
+      int st = d.stuck_ticks[vid] + 1;
+      d.stuck_ticks[vid] = st;
+      if (st > P.stuck_recompute_threshold && !(f & VF_STUCK)) {
+        atomicAdd((unsigned long long*)&d.cnt->stuck, 1ULL);
+        f |= VF_STUCK;
+      }
+    }
+  }
+  if (pos == d.target[vid]) on_target_reached_dev(d, P, vid, s, pos, f, elapsed_now);
+  d.flags[vid] = f;
+}
+
+__device__ __forceinline__ void light_set(const Dev& d, int l, int8_t v) {  // cell.py:241-251
+  d.stop[d.light_cell[l]] = v;
+  for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) d.stop[d.light_ctrl[k]] = v;
+}
+__device__ __forceinline__ int queue_sum(const Dev& d, const int32_t* off, const int32_t* cells, int g) {
+  int q = 0;  // compute_approach_queue (numba_utilities.py:65-72)
+  for (int k = off[g]; k < off[g + 1]; k++) q += d.occ[cells[k]];
+  return q;
+}
+__device__ __forceinline__ void apply_phase(int& cur, int& pend, int phase) {  // intersection_light_group.py:386-393
+  if (phase == cur || phase == pend) return;
+  pend = phase;
+}
+
+// IntersectionLightGroup.step (intersection_light_group.py:396-423) and _execute_phase_change (348-384)
+__device__ void group_step_dev(const Dev& d, const TsParams& P, int g) {
+  int cur = d.gs_cur[g], pend = d.gs_pend[g];
+  if (pend < 0) {
+    switch (P.light_algorithm) {
+      case TS_LIGHTS_FIXED_TIME: {
+        int t = d.gs_fttimer[g] + 1, ph = d.gs_ftphase[g];
+        if (t == 1) apply_phase(cur, pend, ph);
+        if (t >= P.green_duration) { ph = 1 - ph; t = 0; }
+        d.gs_fttimer[g] = t; d.gs_ftphase[g] = ph;
+        break;
+      }
+      case TS_LIGHTS_QUEUE_ACTUATED: {
+        int qt = d.gs_qtimer[g] + 1, gap = d.gs_gap[g], last = d.gs_last[g];
+        int ns_q = queue_sum(d, d.g_nsin_off, d.g_nsin, g), ew_q = queue_sum(d, d.g_ewin_off, d.g_ewin, g);
+        int cq = cur == 0 ? ns_q : ew_q, oq = cur == 0 ? ew_q : ns_q;
+        if (qt == 1) { last = cq; gap = 0; }
+        if (cq > last) { last = cq; gap = 0; } else gap += 1;
+        if (qt >= P.qa_min_green && (gap >= P.qa_gap || qt >= P.qa_max_green || (oq > cq && cq == 0))) {
+          apply_phase(cur, pend, 1 - cur);
+          qt = 0;
+        }
+        d.gs_qtimer[g] = qt; d.gs_gap[g] = gap; d.gs_last[g] = last;
+        break;
+      }
+      case TS_LIGHTS_PRESSURE_CONTROL:
+      case TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL: {
+        int ns_p = queue_sum(d, d.g_nsin_off, d.g_nsin, g) - queue_sum(d, d.g_nsout_off, d.g_nsout, g);
+        int ew_p = queue_sum(d, d.g_ewin_off, d.g_ewin, g) - queue_sum(d, d.g_ewout_off, d.g_ewout, g);
+        if (P.light_algorithm == TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL) {
+          const int32_t* nb = d.gs_repop[g] ? d.g_nb : d.g_nb_ctor;
+          for (int k = 0; k < 4; k++) {
+            int nd = nb[(g * 4 + k) * 2], n = nb[(g * 4 + k) * 2 + 1];
+            if (nd < 0 || n < 0) continue;
+            if (nd == 0 || nd == 2) ns_p -= d.gs_nsp[n]; else ew_p -= d.gs_ewp[n];
+          }
+        }
+        d.gs_nsp[g] = ns_p; d.gs_ewp[g] = ew_p;
+        apply_phase(cur, pend, ns_p > ew_p ? 0 : 1);
+        break;
+      }
+      case TS_LIGHTS_NEIGHBOR_GREEN_WAVE: {
+        int ns_q = queue_sum(d, d.g_nsin_off, d.g_nsin, g), ew_q = queue_sum(d, d.g_ewin_off, d.g_ewin, g);
+        bool fns = false, few = false;
+        const int32_t* nb = d.gs_repop[g] ? d.g_nb : d.g_nb_ctor;
+        for (int k = 0; k < 4; k++) {
+          int nd = nb[(g * 4 + k) * 2], n = nb[(g * 4 + k) * 2 + 1];
+          if (nd < 0 || n < 0) continue;
+          if ((nd == 0 || nd == 2) && d.gs_cur[n] == 0) fns = true;
+          if ((nd == 1 || nd == 3) && d.gs_cur[n] == 1) few = true;
+        }
+        if (fns && !few) apply_phase(cur, pend, 0);
+        else if (few && !fns) apply_phase(cur, pend, 1);
+        else apply_phase(cur, pend, ns_q > ew_q ? 0 : 1);
+        break;
+      }
+      default: break;
+    }
+  }
+  if (pend >= 0) {
+    bool done = false;
+    if (P.transition_duration_enabled && d.gs_trans[g] > 0) {
+      d.gs_trans[g] -= 1;
+      for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1]; l++) light_set(d, l, 1);
+      done = true;
+    }
+    if (!done && P.transition_clearance_enabled) {
+      bool occupied = false;  // is_intersection_occupied (285-291)
+      for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1]; k++) if (d.occ[d.g_icell[k]]) { occupied = true; break; }
+      if (occupied) {
+        for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1]; l++) light_set(d, l, 1);
+        done = true;
+      }
+    }
+    if (!done) {
+      if (P.transition_duration_enabled && d.gs_clear[g] > 0) d.gs_trans[g] = P.all_red_duration;
+      d.gs_repop[g] = 1;  // get_opposite_traffic_lights() re-ran populate_links() (303-307)
+      const int32_t *go_off = pend == 0 ? d.g_ns_off : d.g_ew_off, *go = pend == 0 ? d.g_ns : d.g_ew;
+      const int32_t *st_off = pend == 0 ? d.g_ew_off : d.g_ns_off, *st = pend == 0 ? d.g_ew : d.g_ns;
+      for (int k = go_off[g]; k < go_off[g + 1]; k++) light_set(d, go[k], 0);
+      for (int k = st_off[g]; k < st_off[g + 1]; k++) light_set(d, st[k], 1);
+      cur = pend; pend = -1;
+    }
+  }
+  d.gs_cur[g] = cur; d.gs_pend[g] = pend;
+}
+
+// An agent steps in this round iff no unresolved agent of lower rank claims a cell it reads or writes.
+__global__ void k_move_resolve(Dev d, TsParams P, int n_sched, uint32_t prefix, uint32_t rank_clock, double elapsed0) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_sched || d.resolved[s]) return;
+  const int8_t kind = d.sched_kind[s];
+  const uint32_t r = d.rank[s];
+  bool safe = true;
+  if (kind == K_VEHICLE) {
+    const int vid = d.sched_ref[s];
+    const uint16_t f = d.flags[vid];
+    const int pos = d.pos[vid];
+    const bool lights = d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED;
+    if (f & VF_EARLY) {
+      if (lights && claim_rank(d.cw_stop[pos], prefix) < r) safe = false;
+      if (pos == d.target[vid] && (claim_rank(d.cw_occ[pos], prefix) < r || claim_rank(d.cr_occ[pos], prefix) < r))
+        safe = false;
+    } else {
+      const int m = d.max_steps[vid];
+      if (claim_rank(d.cw_occ[pos], prefix) < r || claim_rank(d.cr_occ[pos], prefix) < r) safe = false;
+      const uint32_t off = d.path_off[vid];
+      const int pcur = d.path_cur[vid];
+      int c = pos;
+      for (int k = 0; k < m && safe; k++) {
+        c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
+        if (claim_rank(d.cw_occ[c], prefix) < r || claim_rank(d.cr_occ[c], prefix) < r) safe = false;
+        if (lights && claim_rank(d.cw_stop[c], prefix) < r) safe = false;
+      }
+    }
+    if (!safe) return;
+    vehicle_step_dev(d, P, vid, s, elapsed0 + (r > rank_clock ? (double)P.time_per_step_seconds : 0.0));
+  } else if (kind == TS_AGENT_LIGHT_GROUP && P.light_algorithm != TS_LIGHTS_DISABLED) {
+    const int g = d.sched_ref[s];
+    for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1] && safe; k++)
+      if (claim_rank(d.cw_occ[d.g_icell[k]], prefix) < r) safe = false;
+    for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1] && safe; k++)
+      if (claim_rank(d.cw_occ[d.g_nsin[k]], prefix) < r) safe = false;
+    for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1] && safe; k++)
+      if (claim_rank(d.cw_occ[d.g_ewin[k]], prefix) < r) safe = false;
+    if (group_reads_out(P)) {
+      for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1] && safe; k++)
+        if (claim_rank(d.cw_occ[d.g_nsout[k]], prefix) < r) safe = false;
+      for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1] && safe; k++)
+        if (claim_rank(d.cw_occ[d.g_ewout[k]], prefix) < r) safe = false;
+    }
+    for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1] && safe; l++) {
+      int lc = d.light_cell[l];
+      if (claim_rank(d.cw_stop[lc], prefix) < r || claim_rank(d.cr_stop[lc], prefix) < r) safe = false;
+      for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1] && safe; k++) {
+        int cc = d.light_ctrl[k];
+        if (claim_rank(d.cw_stop[cc], prefix) < r || claim_rank(d.cr_stop[cc], prefix) < r) safe = false;
+      }
+    }
+    if (safe && group_reads_neighbors(P)) {
+      for (int k = 0; k < 4 && safe; k++) {
+        for (int w = 0; w < 2; w++) {
+          int n = (w ? d.g_nb_ctor : d.g_nb)[(g * 4 + k) * 2 + 1];
+          if (n < 0) continue;
+          int ns = d.g_slot[n];
+          if (!d.resolved[ns] && d.rank[ns] < r) safe = false;  // the neighbour writes its state first
+        }
+      }
+      if (claim_rank(d.gclaim_r[g], prefix) < r) safe = false;  // a lower-ranked group still has to read mine
+    }
+    if (!safe) return;
+    group_step_dev(d, P, g);
+  }
+  d.resolved[s] = 1;
+  atomicAdd(&d.cnt->resolved, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stable compaction of the two ordered lists after despawns (ballot/popc within a wave, block scan in LDS)
+// ---------------------------------------------------------------------------------------------
+constexpr int CITEMS = 4;  // elements per thread
+__global__ void k_compact_count(const int32_t* active, const int8_t* kind, int n, int which, int* block_counts) {
+  __shared__ int wsum[BLK / 64];
+  int base = blockIdx.x * BLK * CITEMS;
+  int c = 0;
+  for (int j = 0; j < CITEMS; j++) {
+    int i = base + j * BLK + threadIdx.x;
+    if (i < n) c += which == 0 ? (active[i] >= 0) : (kind[i] != K_DEAD);
+  }
+  for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < BLK / 64; w++) t += wsum[w]; block_counts[blockIdx.x] = t; }
+}
+__global__ void k_scan_blocks(int* block_counts, int nb, int* total) {  // single block, exclusive scan in place
+  __shared__ int carry;
+  __shared__ int buf[1024];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = i < nb ? block_counts[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nb) block_counts[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += buf[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+// Rows are visited j-major inside a block, so the block's output order is preserved by scanning each
+// j-slab in turn (slab = BLK consecutive elements).
+__global__ void k_compact_scatter(Dev d, int n, int which, const int* block_off, int32_t* out_a, int8_t* out_kind,
+                                  int32_t* out_ref) {
+  __shared__ int wcnt[BLK / 64];
+  __shared__ int running;
+  if (threadIdx.x == 0) running = block_off[blockIdx.x];
+  __syncthreads();
+  int base = blockIdx.x * BLK * CITEMS;
+  for (int j = 0; j < CITEMS; j++) {
+    int i = base + j * BLK + threadIdx.x;
+    bool keep = false;
+    if (i < n) keep = which == 0 ? (d.active[i] >= 0) : (d.sched_kind[i] != K_DEAD);
+    unsigned long long m = __ballot(keep);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int before = __popcll(m & ((1ULL << lane) - 1));
+    if (lane == 0) wcnt[w] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < w; q++) woff += wcnt[q];
+    int dst = running + woff + before;
+    if (keep) {
+      if (which == 0) {
+        int vid = d.active[i];
+        out_a[dst] = vid;
+        d.active_idx[vid] = dst;
+      } else {
+        int8_t k = d.sched_kind[i];
+        int ref = d.sched_ref[i];
+        out_kind[dst] = k; out_ref[dst] = ref;
+        if (k == K_VEHICLE) d.sched_slot[ref] = dst;
+        else if (k == TS_AGENT_LIGHT_GROUP) d.g_slot[ref] = dst;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < BLK / 64; q++) t += wcnt[q]; running += t; }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// spawn, read-back and density kernels
+// ---------------------------------------------------------------------------------------------
+struct SpawnArgs {
+  const int32_t *start, *goal, *pop, *plen;
+  const uint32_t* poff;
+  const uint8_t* serial;  // 1 = start cell shared inside the batch -> placed by the serial kernel
+};
+__global__ void k_spawn(Dev d, TsParams P, SpawnArgs a, int n, int vid0, int active0, int sched0, double elapsed,
+                        int* overflow, int* n_overflow) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int vid = vid0 + i;
+  int pos = a.start[i];
+  d.pos[vid] = pos; d.target[vid] = a.goal[i];
+  d.path_off[vid] = a.poff[i]; d.path_len[vid] = a.plen[i]; d.path_cur[vid] = 0;
+  d.stuck_ticks[vid] = 0; d.cooldown[vid] = P.pathfinding_cooldown; d.stranded_left[vid] = 0; d.steps[vid] = 0;
+  d.over_dur[vid] = -1; d.det_dur[vid] = -1; d.next_in_cell[vid] = -1;
+  d.base_speed[vid] = 0; d.cur_speed[vid] = 0; d.max_steps[vid] = 0; d.dir[vid] = -1; d.pop[vid] = (int8_t)a.pop[i];
+  d.flags[vid] = VF_ALIVE; d.depart[vid] = P.enable_traffic ? elapsed : 0.0;
+  d.ev[vid] = 0; d.st_before[vid] = 0; d.st_after[vid] = 0;
+  d.active[active0 + i] = vid; d.active_idx[vid] = active0 + i;
+  d.sched_kind[sched0 + i] = K_VEHICLE; d.sched_ref[sched0 + i] = vid; d.sched_slot[vid] = sched0 + i;
+  d.occ[pos] = 1; d.stuck[pos] = 0;  // place_vehicle (city_model.py:1897-1918)
+  if (a.serial[i] || atomicCAS(&d.cell_veh[pos], -1, vid) != -1) overflow[atomicAdd(n_overflow, 1)] = vid;
+}
+__global__ void k_spawn_serial(Dev d, int* overflow, int n_overflow) {  // cells holding several vehicles: list order = spawn order
+  if (threadIdx.x || blockIdx.x) return;
+  for (int a = 1; a < n_overflow; a++) {  // insertion sort by vehicle id (tiny)
+    int v = overflow[a], b = a - 1;
+    while (b >= 0 && overflow[b] > v) { overflow[b + 1] = overflow[b]; b--; }
+    overflow[b + 1] = v;
+  }
+  for (int a = 0; a < n_overflow; a++) cell_append(d, d.pos[overflow[a]], overflow[a]);
+}
+
+__global__ void k_rows(Dev d, int n_active, const uint32_t* crc_table, int32_t* rows) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_active) return;
+  int vid = d.active[i];
+  int32_t* r = rows + (size_t)i * TS_V_NFIELDS;
+  int pos = d.pos[vid];
+  r[TS_V_SPAWN_IDX] = vid; r[TS_V_X] = pos % d.W; r[TS_V_Y] = pos / d.W;
+  r[TS_V_BASE_SPEED] = d.base_speed[vid]; r[TS_V_CURRENT_SPEED] = d.cur_speed[vid]; r[TS_V_MAX_STEPS] = d.max_steps[vid];
+  r[TS_V_DIRECTION] = d.dir[vid]; r[TS_V_STUCK_TICKS] = d.stuck_ticks[vid]; r[TS_V_COOLDOWN] = d.cooldown[vid];
+  r[TS_V_FLAGS] = d.flags[vid] & 0x1FF; r[TS_V_STRANDED_LEFT] = d.stranded_left[vid];
+  r[TS_V_STEPS_TRAVELED] = d.steps[vid];
+  int pcur = d.path_cur[vid], plen = d.path_len[vid] - pcur;
+  r[TS_V_PATH_LEN] = plen;
+  uint32_t crc = 0;
+  if (plen > 0) {
+    crc = 0xFFFFFFFFu;
+    int c = pos;
+    uint32_t off = d.path_off[vid];
+    for (int k = 0; k < plen; k++) {
+      c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
+      int32_t xy[2] = {c % d.W, c / d.W};
+      const uint8_t* p = (const uint8_t*)xy;
+      for (int b = 0; b < 8; b++) crc = crc_table[(crc ^ p[b]) & 0xff] ^ (crc >> 8);
+    }
+    crc ^= 0xFFFFFFFFu;
+  }
+  r[TS_V_PATH_CRC] = (int32_t)crc;
+  r[TS_V_OVERTAKE_DUR] = d.over_dur[vid]; r[TS_V_DETOUR_DUR] = d.det_dur[vid];
+}
+__global__ void k_path_cells(Dev d, int vid, int32_t* xy) {
+  if (threadIdx.x || blockIdx.x) return;
+  int pcur = d.path_cur[vid], plen = d.path_len[vid] - pcur, c = d.pos[vid];
+  uint32_t off = d.path_off[vid];
+  for (int k = 0; k < plen; k++) {
+    c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
+    xy[2 * k] = c % d.W; xy[2 * k + 1] = c / d.W;
+  }
+}
+__global__ void k_group_rows(Dev d, int32_t* rows) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= d.G) return;
+  int32_t* r = rows + (size_t)g * TS_G_NFIELDS;
+  r[TS_G_CURRENT_PHASE] = d.gs_cur[g]; r[TS_G_PENDING_PHASE] = d.gs_pend[g]; r[TS_G_QUEUE_TIMER] = d.gs_qtimer[g];
+  r[TS_G_GAP_TIMER] = d.gs_gap[g]; r[TS_G_LAST_ARRIVAL] = d.gs_last[g]; r[TS_G_FIXED_TIME_TIMER] = d.gs_fttimer[g];
+  r[TS_G_FT_PHASE] = d.gs_ftphase[g]; r[TS_G_NS_PRESSURE] = d.gs_nsp[g]; r[TS_G_EW_PRESSURE] = d.gs_ewp[g];
+}
+
+// _update_density_map (city_model.py:1764-1778): scipy.ndimage.uniform_filter on float32 = two 1-D passes
+// with double accumulators and a float32 intermediate; `* 441` and the division in float32.
+__global__ void k_density_pass0(const int8_t* occ, const int8_t* road, int W, int H, int r, float* t_occ, float* t_road) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= W * H) return;
+  int x = i % W, y = i / W;
+  int y0 = max(0, y - r), y1 = min(H - 1, y + r);
+  int c0 = 0, c1 = 0;
+  for (int yy = y0; yy <= y1; yy++) { c0 += occ[yy * W + x]; c1 += road[yy * W + x]; }
+  const double size = (double)(2 * r + 1);
+  t_occ[i] = (float)((double)c0 / size);
+  t_road[i] = (float)((double)c1 / size);
+}
+__global__ void k_density_pass1(const float* t_occ, const float* t_road, int W, int H, int r, float* density) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= W * H) return;
+  int x = i % W, y = i / W;
+  int x0 = max(0, x - r), x1 = min(W - 1, x + r);
+  double s0 = 0.0, s1 = 0.0;
+  for (int xx = x0; xx <= x1; xx++) { s0 += (double)t_occ[y * W + xx]; s1 += (double)t_road[y * W + xx]; }
+  const double size = (double)(2 * r + 1);
+  const float area = (float)((2 * r + 1) * (2 * r + 1));
+  float v0 = (float)(s0 / size) * area, v1 = (float)(s1 / size) * area;
+  density[i] = v1 > 0.f ? __fdiv_rn(v0, v1) : 0.f;
+}
+
+template <typename T>
+__global__ void k_fill(T* p, T v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+inline int nblk(long long n, int per = BLK) { return (int)((n + per - 1) / per); }
+
+}  // namespace
+
+// =============================================================================================
+// host side
+// =============================================================================================
+struct ts_engine {
+  TsParams P;
+  Dev d;
+  int W = 0, H = 0, N = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // capacities
+  int cap_v = 0, cap_sched = 0;
+  size_t pool_cap = 0, pool_used = 0;
+  int n_vehicles_total = 0;  // vehicle ids handed out
+  int n_active = 0, n_sched = 0;
+  int n_sched_vehicles = 0;
+  int clock_slot = -1;
+  bool mixed_order = false;  // a non-vehicle agent was scheduled after a vehicle
+  int groups_scheduled = 0;
+  bool lights_set = false;
+  // double buffers for compaction
+  int32_t* active_alt = nullptr;
+  int8_t* kind_alt = nullptr;
+  int32_t* ref_alt = nullptr;
+  int* block_counts = nullptr;
+  int cap_blocks = 0;
+  int* d_total = nullptr;
+  uint32_t* d_crc = nullptr;
+  int* d_overflow = nullptr;
+  int cap_overflow = 0;
+  // pinned host staging
+  uint8_t *hF = nullptr, *hR = nullptr;
+  uint32_t* hrank = nullptr;
+  DevCnt* hcnt = nullptr;
+  int* hint = nullptr;
+  int cap_host = 0;
+  // RNG streams (host)
+  HostMT rng_global, rng_sched;
+  bool seeded[2] = {false, false};
+  uint32_t epoch = 0;
+  TsCounters C;
+  std::vector<uint32_t> perm;
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+typedef ts_engine E;
+
+int fail(E* e, int code, const std::string& msg) {
+  if (e) e->err = msg;
+  return code;
+}
+#define HIPOK(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess)                                                                             \
+      return fail(e, TS_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+  } while (0)
+
+template <typename T>
+hipError_t dalloc(E* e, T** p, size_t n) {
+  hipError_t r = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+  if (r == hipSuccess) e->allocs.push_back((void*)*p);
+  return r;
+}
+void dfree(E* e, void* p) {
+  if (!p) return;
+  auto it = std::find(e->allocs.begin(), e->allocs.end(), p);
+  if (it != e->allocs.end()) e->allocs.erase(it);
+  (void)hipFree(p);
+}
+// grow a device array, preserving `keep` elements
+template <typename T>
+int regrow(E* e, T** p, size_t keep, size_t n) {
+  T* q = nullptr;
+  HIPOK(dalloc(e, &q, n));
+  if (*p && keep) HIPOK(hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  dfree(e, *p);
+  *p = q;
+  return TS_OK;
+}
+
+int ensure_vehicle_capacity(E* e, int need_v, int need_sched) {
+  if (need_v > e->cap_v) {
+    int nc = std::max(need_v, e->cap_v * 2 + 1024);
+    Dev& d = e->d;
+    size_t k = e->n_vehicles_total;
+#define RG(field) { int rc = regrow(e, &d.field, k, (size_t)nc); if (rc) return rc; }
+    RG(pos) RG(target) RG(path_len) RG(path_cur) RG(stuck_ticks) RG(cooldown) RG(stranded_left) RG(steps) RG(over_dur)
+    RG(det_dur) RG(next_in_cell) RG(active_idx) RG(sched_slot) RG(path_off) RG(base_speed) RG(cur_speed) RG(max_steps)
+    RG(dir) RG(pop) RG(flags) RG(depart) RG(ev) RG(st_before) RG(st_after)
+#undef RG
+    { int rc = regrow(e, &d.active, (size_t)e->n_active, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &e->active_alt, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &d.F, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &d.R, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &d.cand, 0, (size_t)nc); if (rc) return rc; }
+    e->cap_v = nc;
+  }
+  if (need_sched > e->cap_sched) {
+    int nc = std::max(need_sched, e->cap_sched * 2 + 1024);
+    Dev& d = e->d;
+    { int rc = regrow(e, &d.sched_kind, (size_t)e->n_sched, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &d.sched_ref, (size_t)e->n_sched, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &d.rank, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &d.resolved, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &e->kind_alt, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &e->ref_alt, 0, (size_t)nc); if (rc) return rc; }
+    e->cap_sched = nc;
+  }
+  int need_host = std::max(need_v, need_sched);
+  if (need_host > e->cap_host) {
+    int nc = std::max(need_host, e->cap_host * 2 + 1024);
+    if (e->hF) (void)hipHostFree(e->hF);
+    if (e->hR) (void)hipHostFree(e->hR);
+    if (e->hrank) (void)hipHostFree(e->hrank);
+    HIPOK(hipHostMalloc((void**)&e->hF, nc));
+    HIPOK(hipHostMalloc((void**)&e->hR, nc));
+    HIPOK(hipHostMalloc((void**)&e->hrank, (size_t)nc * 4));
+    e->cap_host = nc;
+  }
+  int need_blocks = nblk(std::max(e->cap_v, e->cap_sched), BLK * CITEMS) + 1;
+  if (need_blocks > e->cap_blocks) {
+    { int rc = regrow(e, &e->block_counts, 0, (size_t)need_blocks); if (rc) return rc; }
+    e->cap_blocks = need_blocks;
+  }
+  return TS_OK;
+}
+
+int ensure_pool(E* e, size_t need_words) {
+  if (need_words <= e->pool_cap) return TS_OK;
+  size_t nc = std::max(need_words, e->pool_cap * 2 + (1u << 16));
+  if (nc >= (1ull << 32)) return fail(e, TS_E_CAPACITY, "path pool exceeds 2^32 words");
+  int rc = regrow(e, &e->d.pool, e->pool_used, nc);
+  if (rc) return rc;
+  e->pool_cap = nc;
+  return TS_OK;
+}
+
+int sync_counters(E* e) {  // device counters -> e->C
+  HIPOK(hipMemcpyAsync(e->hcnt, e->d.cnt, sizeof(DevCnt), hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  const DevCnt& c = *e->hcnt;
+  e->C.stuck = c.stuck; e->C.collisions = c.collisions; e->C.malfunctions = c.malfunctions;
+  e->C.overtaking = c.overtaking; e->C.in_stuck_detour = c.in_stuck_detour; e->C.parked = c.parked;
+  e->C.live_internal = c.live_internal; e->C.live_through = c.live_through;
+  e->C.count_completed_internal = c.completed_internal; e->C.count_completed_through = c.completed_through;
+  e->C.total_distance_internal = c.dist_internal; e->C.total_distance_through = c.dist_through;
+  e->C.total_duration_internal = c.dur_internal; e->C.total_duration_through = c.dur_through;
+  return TS_OK;
+}
+
+// stable compaction of active_vehicle_agents (which = 0) or the schedule (which = 1); returns new length
+int compact(E* e, int which, int n, int* out_n) {
+  Dev& d = e->d;
+  int nb = nblk(n, BLK * CITEMS);
+  if (n == 0) { *out_n = 0; return TS_OK; }
+  hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(BLK), 0, e->stream, d.active, d.sched_kind, n, which, e->block_counts);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, e->block_counts, nb, e->d_total);
+  hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(BLK), 0, e->stream, d, n, which, e->block_counts, e->active_alt,
+                     e->kind_alt, e->ref_alt);
+  HIPOK(hipMemcpyAsync(e->hint, e->d_total, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  *out_n = e->hint[0];
+  if (which == 0) std::swap(d.active, e->active_alt);
+  else { std::swap(d.sched_kind, e->kind_alt); std::swap(d.sched_ref, e->ref_alt); }
+  return TS_OK;
+}
+
+// random.shuffle(keys) with model.random, then rank[slot] = position in the shuffled order (A4)
+void shuffle_ranks(E* e, int n) {
+  e->perm.resize(n);
+  uint32_t* p = e->perm.data();
+  for (int i = 0; i < n; i++) p[i] = (uint32_t)i;
+  HostMT& r = e->rng_sched;
+  for (int i = n - 1; i >= 1; i--) {
+    uint32_t j = r.randbelow((uint32_t)(i + 1));
+    uint32_t t = p[i]; p[i] = p[j]; p[j] = t;
+  }
+  for (int q = 0; q < n; q++) e->hrank[p[q]] = (uint32_t)q;
+}
+
+int tick(E* e) {
+  Dev& d = e->d;
+  const TsParams& P = e->P;
+  hipStream_t st = e->stream;
+  const int nA = e->n_active, nS = e->n_sched;
+  // the scheduler stream is independent of everything the decide phase does: shuffle on a host thread
+  std::thread shuffler([e, nS]() { shuffle_ranks(e, nS); });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{shuffler};
+
+  // ---------------- decide ----------------
+  if (nA > 0) {
+    HIPOK(hipMemsetAsync(d.ev, 0, (size_t)e->n_vehicles_total, st));
+    int start = 0;
+    int i = 0;
+    memset(e->hR, 0, nA);
+    while (true) {
+      int cnt = nA - start;
+      if (cnt > 0) {
+        hipLaunchKernelGGL(k_decide_pre, dim3(nblk(cnt)), dim3(BLK), 0, st, d, P, start, nA);
+        hipLaunchKernelGGL(k_decide_pre2, dim3(nblk(cnt)), dim3(BLK), 0, st, d, P, start, nA);
+        HIPOK(hipMemcpyAsync(e->hF + start, d.F + start, cnt, hipMemcpyDeviceToHost, st));
+      }
+      HIPOK(hipStreamSynchronize(st));
+      // host scan of the global MT19937 stream in active_vehicle_agents order (A7, A8)
+      HostMT& r = e->rng_global;
+      int ev_at = -1, ev_coll = 0;
+      const uint8_t* F = e->hF;
+      uint8_t* R = e->hR;
+      for (; i < nA; i++) {
+        uint8_t f = F[i];
+        if (!f) continue;
+        if (f & F_DRAW_MALF) {
+          if (r.random() < P.malfunction_chance) { ev_at = i; ev_coll = 0; break; }
+        }
+        if (f & F_DRAW_SWIPE) {
+          if (!(r.random() >= P.sideswipe_chance)) { ev_at = i; ev_coll = 1; break; }
+        }
+        if (f & F_DRAW_SPEED) R[i] = (uint8_t)r.randint(P.vehicle_min_speed, P.vehicle_max_speed);
+      }
+      if (ev_at < 0) break;
+      // rare: a malfunction / sideswipe fired.  Apply it and re-derive the draw flags of the suffix.
+      e->C.rng_fixups++;
+      int ids[2];
+      HIPOK(hipMemcpyAsync(&e->hint[0], d.active + ev_at, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPOK(hipMemcpyAsync(&e->hint[1], d.cand + ev_at, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPOK(hipStreamSynchronize(st));
+      ids[0] = e->hint[0]; ids[1] = e->hint[1];
+      hipLaunchKernelGGL(k_apply_event, dim3(1), dim3(64), 0, st, d, P, ids[0], ev_coll, ids[1], ev_at);
+      i = ev_at + 1;
+      start = i;
+    }
+    HIPOK(hipMemcpyAsync(d.R, e->hR, nA, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_decide_main, dim3(nblk(nA)), dim3(BLK), 0, st, d, P, nA);
+  }
+
+  // ---------------- move (schedule.step) ----------------
+  shuffler.join();
+  const uint32_t rank_clock = e->clock_slot >= 0 ? e->hrank[e->clock_slot] : NO_RANK;
+  const double elapsed0 = e->C.elapsed;
+  if (nS > 0) {
+    HIPOK(hipMemcpyAsync(d.rank, e->hrank, (size_t)nS * 4, hipMemcpyHostToDevice, st));
+    HIPOK(hipMemsetAsync(d.resolved, 0, (size_t)nS, st));
+    HIPOK(hipMemsetAsync(&d.cnt->resolved, 0, sizeof(int) * 2, st));  // resolved, deaths
+    int done = 0, chunk = 2;
+    while (done < nS) {
+      for (int rr = 0; rr < chunk; rr++) {
+        if ((e->epoch % EPOCHS) == 0) {  // epoch prefix wrapped: stale keys would win again -> clear once
+          size_t n = (size_t)e->N;
+          HIPOK(hipMemsetAsync(d.cw_occ, 0xFF, n * 4, st));
+          HIPOK(hipMemsetAsync(d.cr_occ, 0xFF, n * 4, st));
+          HIPOK(hipMemsetAsync(d.cw_stop, 0xFF, n * 4, st));
+          HIPOK(hipMemsetAsync(d.cr_stop, 0xFF, n * 4, st));
+          HIPOK(hipMemsetAsync(d.gclaim_r, 0xFF, (size_t)std::max(d.G, 1) * 4, st));
+        }
+        const uint32_t prefix = (EPOCHS - 1) - (e->epoch % EPOCHS);
+        e->epoch++;
+        hipLaunchKernelGGL(k_move_claim, dim3(nblk(nS)), dim3(BLK), 0, st, d, P, nS, prefix);
+        hipLaunchKernelGGL(k_move_resolve, dim3(nblk(nS)), dim3(BLK), 0, st, d, P, nS, prefix, rank_clock, elapsed0);
+        e->C.move_rounds++;
+      }
+      HIPOK(hipMemcpyAsync(e->hint, &d.cnt->resolved, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+      HIPOK(hipStreamSynchronize(st));
+      int now = e->hint[0];
+      if (now == done && now < nS) return fail(e, TS_E_DEVICE, "move phase made no progress (internal error)");
+      done = now;
+      chunk = 4;
+    }
+    if (e->hint[3]) return fail(e, e->hint[3], "device-side error: a vehicle sits on its target during decide (start == goal is not supported)");
+    if (e->hint[2]) return fail(e, TS_E_UNSUPPORTED, "a vehicle requested a replan but the GPU A* is not built yet");
+    e->C.agent_steps += e->n_sched_vehicles;
+    const int deaths = e->hint[1];
+    if (deaths > 0) {
+      int na = 0, ns = 0;
+      int rc = compact(e, 0, nA, &na); if (rc) return rc;
+      rc = compact(e, 1, nS, &ns); if (rc) return rc;
+      e->n_active = na; e->n_sched = ns; e->n_sched_vehicles -= deaths;
+      if (e->clock_slot >= 0 && e->mixed_order) {
+        // the clock never dies, but dead vehicles scheduled before it shift its slot: find it again
+        std::vector<int8_t> kinds(ns);
+        HIPOK(hipMemcpy(kinds.data(), d.sched_kind, ns, hipMemcpyDeviceToHost));
+        e->clock_slot = -1;
+        for (int q = 0; q < ns; q++) if (kinds[q] == TS_AGENT_CLOCK) { e->clock_slot = q; break; }
+      }
+    }
+  }
+  if (e->clock_slot >= 0) e->C.elapsed += P.time_per_step_seconds;
+  e->C.step_count++;
+  return TS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ts_default_params(TsParams* p) {
+  memset(p, 0, sizeof(*p));
+  p->vehicle_min_speed = 1; p->vehicle_max_speed = 5; p->vehicle_awareness_range = 10;
+  p->rain_enabled = 1; p->rain_speed_reduction = 2;
+  p->pathfinding_cooldown = 5; p->pathfinding_cache = 1;
+  p->stuck_recompute_threshold = 30; p->stuck_recompute_threshold_intersection = 1;
+  p->contraflow_overtake_active = 1; p->max_contraflow_overtake_steps = 6; p->contraflow_overtake_duration = 30;
+  p->stuck_contraflow_enabled = 1; p->stuck_contraflow_threshold = 60; p->stuck_contraflow_threshold_intersection = 10;
+  p->max_contraflow_stuck_detour_steps = 20; p->contraflow_stuck_detour_duration = 10;
+  p->malfunction_active = 1; p->malfunction_duration = 400; p->malfunction_chance = 1e-7;
+  p->sideswipe_active = 1; p->sideswipe_duration = 600; p->sideswipe_chance = 1e-9;
+  p->contraflow_penalty = 5000; p->obstacle_penalty_vehicle = 1000; p->obstacle_penalty_stop = 500;
+  p->road_type_penalties_enabled = 1; p->turn_penalty_enabled = 1; p->turn_penalty = 10;
+  p->dynamic_penalties_enabled = 1;
+  p->road_type_penalty_r1 = 0.5; p->road_type_penalty_r2 = 5; p->road_type_penalty_r3 = 50.0;
+  p->dynamic_penalty_scale = 4.0;
+  p->light_algorithm = TS_LIGHTS_QUEUE_ACTUATED;
+  p->transition_duration_enabled = 0; p->transition_clearance_enabled = 1; p->all_red_duration = 2;
+  p->green_duration = 20; p->qa_min_green = 5; p->qa_max_green = 30; p->qa_gap = 3;
+  p->enable_traffic = 1; p->time_per_step_seconds = 6; p->eager_density = 0;
+}
+
+int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
+  if (!w || !params || !out || w->width <= 0 || w->height <= 0 || !w->allowed_dirs_map || !w->is_road_map ||
+      !w->road_type_map || !w->intersection_map)
+    return TS_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return TS_E_DEVICE;
+  E* e = new E();
+  memset(&e->d, 0, sizeof(e->d));
+  memset(&e->C, 0, sizeof(e->C));
+  e->P = *params;
+  e->W = w->width; e->H = w->height; e->N = w->width * w->height;
+  Dev& d = e->d;
+  d.W = e->W; d.H = e->H; d.N = e->N;
+  size_t N = e->N;
+  auto bail = [&](int code) { ts_destroy(e); return code; };
+  if (hipStreamCreate(&e->stream) != hipSuccess) return bail(TS_E_DEVICE);
+#define A(ptr, n) if (dalloc(e, &ptr, (size_t)(n)) != hipSuccess) return bail(TS_E_DEVICE);
+  A(d.occ, N) A(d.stop, N) A(d.stuck, N) A(d.rain, N) A(d.allowed, N) A(d.is_road, N) A(d.road_type, N) A(d.inter, N)
+  A(d.cell_veh, N) A(d.cw_occ, N) A(d.cr_occ, N) A(d.cw_stop, N) A(d.cr_stop, N) A(d.gclaim_r, 1)
+  A(d.cnt, 1) A(e->d_total, 1) A(e->d_crc, 256)
+#undef A
+  hipStream_t st = e->stream;
+  bool ok = true;
+  ok &= hipMemsetAsync(d.occ, 0, N, st) == hipSuccess;
+  ok &= hipMemsetAsync(d.stop, 0, N, st) == hipSuccess;
+  ok &= hipMemsetAsync(d.stuck, 0, N, st) == hipSuccess;
+  ok &= hipMemsetAsync(d.rain, 0, N, st) == hipSuccess;
+  ok &= hipMemsetAsync(d.cell_veh, 0xFF, N * 4, st) == hipSuccess;
+  ok &= hipMemsetAsync(d.cnt, 0, sizeof(DevCnt), st) == hipSuccess;
+  ok &= hipMemcpyAsync(d.allowed, w->allowed_dirs_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(d.is_road, w->is_road_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(d.road_type, w->road_type_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(d.inter, w->intersection_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
+  uint32_t table[256];
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320U ^ (c >> 1)) : (c >> 1);
+    table[i] = c;
+  }
+  ok &= hipMemcpyAsync(e->d_crc, table, sizeof(table), hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipHostMalloc((void**)&e->hcnt, sizeof(DevCnt)) == hipSuccess;
+  ok &= hipHostMalloc((void**)&e->hint, sizeof(int) * 16) == hipSuccess;
+  ok &= hipStreamSynchronize(st) == hipSuccess;
+  if (!ok) return bail(TS_E_DEVICE);
+  e->epoch = 0;
+  if (ensure_vehicle_capacity(e, 1024, 1024) != TS_OK) return bail(TS_E_DEVICE);
+  if (ensure_pool(e, 1 << 16) != TS_OK) return bail(TS_E_DEVICE);
+  *out = e;
+  return TS_OK;
+}
+
+int ts_destroy(ts_handle e) {
+  if (!e) return TS_OK;
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->hF) (void)hipHostFree(e->hF);
+  if (e->hR) (void)hipHostFree(e->hR);
+  if (e->hrank) (void)hipHostFree(e->hrank);
+  if (e->hcnt) (void)hipHostFree(e->hcnt);
+  if (e->hint) (void)hipHostFree(e->hint);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return TS_OK;
+}
+
+const char* ts_last_error(ts_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int ts_set_lights(ts_handle e, const TsLightTables* t) {
+  if (!e || !t || t->n_groups < 0 || t->n_lights < 0) return TS_E_INVALID;
+  if (e->lights_set) return fail(e, TS_E_STATE, "ts_set_lights may be called once");
+  const int W = e->W, H = e->H, G = t->n_groups, L = t->n_lights;
+  Dev& d = e->d;
+  auto cells = [&](const int32_t* xy, int n, std::vector<int32_t>& out) {
+    out.resize(n);
+    for (int i = 0; i < n; i++) {
+      int x = xy[2 * i], y = xy[2 * i + 1];
+      if (x < 0 || x >= W || y < 0 || y >= H) return false;
+      out[i] = y * W + x;
+    }
+    return true;
+  };
+  auto up = [&](int32_t** dst, const int32_t* src, size_t n) -> int {
+    HIPOK(dalloc(e, dst, n));
+    if (n) HIPOK(hipMemcpyAsync(*dst, src, n * 4, hipMemcpyHostToDevice, e->stream));
+    return TS_OK;
+  };
+  std::vector<int32_t> tmp;
+#define UPOFF(dst, src, n) { int rc = up(&d.dst, t->src, (size_t)(n)); if (rc) return rc; }
+#define UPCELLS(dst, src, n) { if (!cells(t->src, (n), tmp)) return fail(e, TS_E_INVALID, #src " out of bounds"); \
+    int rc = up(&d.dst, tmp.data(), (size_t)(n)); if (rc) return rc; HIPOK(hipStreamSynchronize(e->stream)); }
+  UPOFF(g_light_off, g_light_off, G + 1)
+  UPCELLS(light_cell, light_xy, L)
+  UPOFF(light_ctrl_off, light_ctrl_off, L + 1)
+  UPCELLS(light_ctrl, light_ctrl_xy, t->light_ctrl_off[L])
+  UPOFF(g_ns_off, g_ns_off, G + 1) UPOFF(g_ns, g_ns, t->g_ns_off[G])
+  UPOFF(g_ew_off, g_ew_off, G + 1) UPOFF(g_ew, g_ew, t->g_ew_off[G])
+  for (int k = 0; k < t->g_ns_off[G]; k++) if (t->g_ns[k] < 0 || t->g_ns[k] >= L) return fail(e, TS_E_INVALID, "g_ns light index");
+  for (int k = 0; k < t->g_ew_off[G]; k++) if (t->g_ew[k] < 0 || t->g_ew[k] >= L) return fail(e, TS_E_INVALID, "g_ew light index");
+  UPOFF(g_icell_off, g_icell_off, G + 1) UPCELLS(g_icell, g_icell_xy, t->g_icell_off[G])
+  UPOFF(g_nsin_off, g_ns_in_off, G + 1) UPCELLS(g_nsin, g_ns_in_xy, t->g_ns_in_off[G])
+  UPOFF(g_nsout_off, g_ns_out_off, G + 1) UPCELLS(g_nsout, g_ns_out_xy, t->g_ns_out_off[G])
+  UPOFF(g_ewin_off, g_ew_in_off, G + 1) UPCELLS(g_ewin, g_ew_in_xy, t->g_ew_in_off[G])
+  UPOFF(g_ewout_off, g_ew_out_off, G + 1) UPCELLS(g_ewout, g_ew_out_xy, t->g_ew_out_off[G])
+#undef UPOFF
+#undef UPCELLS
+  std::vector<int32_t> nb((size_t)G * 8, -1), nbc((size_t)G * 8, -1);
+  if (t->g_neighbors) nb.assign(t->g_neighbors, t->g_neighbors + (size_t)G * 8);
+  const int32_t* nc = t->g_neighbors_ctor ? t->g_neighbors_ctor : t->g_neighbors;
+  if (nc) nbc.assign(nc, nc + (size_t)G * 8);
+  for (int g = 0; g < G * 4; g++)
+    if (nb[g * 2 + 1] >= G || nbc[g * 2 + 1] >= G) return fail(e, TS_E_INVALID, "neighbor group index out of range");
+  { int rc = up(&d.g_nb, nb.data(), nb.size()); if (rc) return rc; }
+  { int rc = up(&d.g_nb_ctor, nbc.data(), nbc.size()); if (rc) return rc; }
+  HIPOK(hipStreamSynchronize(e->stream));
+  // state: pending_phase = 0 unless DISABLED (intersection_light_group.py:115-116)
+  int32_t** zero_fields[] = {&d.gs_trans, &d.gs_clear, &d.gs_ftphase, &d.gs_fttimer, &d.gs_qtimer, &d.gs_gap,
+                             &d.gs_last, &d.gs_nsp, &d.gs_ewp, &d.gs_repop, &d.g_slot};
+  for (auto f : zero_fields) {
+    HIPOK(dalloc(e, f, (size_t)G));
+    HIPOK(hipMemsetAsync(*f, 0, (size_t)std::max(G, 1) * 4, e->stream));
+  }
+  HIPOK(dalloc(e, &d.gs_cur, (size_t)G));
+  HIPOK(dalloc(e, &d.gs_pend, (size_t)G));
+  HIPOK(hipMemsetAsync(d.gs_cur, 0xFF, (size_t)std::max(G, 1) * 4, e->stream));
+  if (e->P.light_algorithm != TS_LIGHTS_DISABLED) HIPOK(hipMemsetAsync(d.gs_pend, 0, (size_t)std::max(G, 1) * 4, e->stream));
+  else HIPOK(hipMemsetAsync(d.gs_pend, 0xFF, (size_t)std::max(G, 1) * 4, e->stream));
+  dfree(e, d.gclaim_r);
+  d.gclaim_r = nullptr;
+  HIPOK(dalloc(e, &d.gclaim_r, (size_t)G));
+  HIPOK(hipMemsetAsync(d.gclaim_r, 0xFF, (size_t)std::max(G, 1) * 4, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  d.G = G;
+  e->lights_set = true;
+  e->groups_scheduled = 0;
+  return TS_OK;
+}
+
+int ts_schedule_add(ts_handle e, int32_t kind, int32_t count) {
+  if (!e || count < 0) return TS_E_INVALID;
+  if (kind != TS_AGENT_LIGHT_GROUP && kind != TS_AGENT_NOOP && kind != TS_AGENT_CLOCK)
+    return fail(e, TS_E_INVALID, "bad agent kind");
+  if (kind == TS_AGENT_LIGHT_GROUP && e->groups_scheduled + count > e->d.G)
+    return fail(e, TS_E_INVALID, "more group slots than groups");
+  if (kind == TS_AGENT_CLOCK && (count > 1 || e->clock_slot >= 0) && count > 0)
+    return fail(e, TS_E_INVALID, "at most one clock agent");
+  if (count == 0) return TS_OK;
+  if (e->n_sched_vehicles > 0) e->mixed_order = true;
+  int rc = ensure_vehicle_capacity(e, e->cap_v, e->n_sched + count);
+  if (rc) return rc;
+  std::vector<int8_t> kinds(count, (int8_t)kind);
+  std::vector<int32_t> refs(count, 0), slots(count);
+  for (int i = 0; i < count; i++) {
+    if (kind == TS_AGENT_LIGHT_GROUP) refs[i] = e->groups_scheduled + i;
+    slots[i] = e->n_sched + i;
+  }
+  HIPOK(hipMemcpy(e->d.sched_kind + e->n_sched, kinds.data(), count, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(e->d.sched_ref + e->n_sched, refs.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+  if (kind == TS_AGENT_LIGHT_GROUP) {
+    HIPOK(hipMemcpy(e->d.g_slot + e->groups_scheduled, slots.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+    e->groups_scheduled += count;
+  }
+  if (kind == TS_AGENT_CLOCK) e->clock_slot = e->n_sched;
+  e->n_sched += count;
+  return TS_OK;
+}
+
+int ts_seed(ts_handle e, int32_t stream, const uint32_t* mt, uint32_t index) {
+  if (!e || !mt || stream < 0 || stream > 1 || index > 624) return TS_E_INVALID;
+  HostMT& r = stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched;
+  memcpy(r.mt, mt, sizeof(r.mt)); r.idx = index;
+  e->seeded[stream] = true;
+  return TS_OK;
+}
+int ts_seed_int(ts_handle e, int32_t stream, uint64_t seed) {
+  if (!e || stream < 0 || stream > 1) return TS_E_INVALID;
+  (stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched).seed_u64(seed);
+  e->seeded[stream] = true;
+  return TS_OK;
+}
+int ts_rng_state(ts_handle e, int32_t stream, uint32_t* mt_out, uint32_t* index_out) {
+  if (!e || stream < 0 || stream > 1 || !mt_out || !index_out) return TS_E_INVALID;
+  HostMT& r = stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched;
+  memcpy(mt_out, r.mt, sizeof(r.mt)); *index_out = r.idx;
+  return TS_OK;
+}
+
+int ts_add_vehicles(ts_handle e, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
+                    const int32_t* population_type, const int32_t* path_off, const int32_t* path_xy) {
+  if (!e || n < 0 || (n > 0 && (!start_xy || !goal_xy))) return TS_E_INVALID;
+  if (n == 0) return TS_OK;
+  if (!path_off || !path_xy)
+    return fail(e, TS_E_UNSUPPORTED, "initial paths must be supplied until the GPU A* is built");
+  const int W = e->W, H = e->H;
+  if ((long long)e->n_sched + n >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
+  std::vector<int32_t> start(n), goal(n), pop(n), plen(n);
+  std::vector<uint32_t> poff(n);
+  // encode paths as 2-bit directions; every vehicle starts on a fresh 32-bit word
+  size_t words = 0;
+  for (int i = 0; i < n; i++) words += ((size_t)(path_off[i + 1] - path_off[i]) + 15) / 16;
+  std::vector<uint32_t> enc(words, 0);
+  size_t wpos = 0;
+  for (int i = 0; i < n; i++) {
+    int sx = start_xy[2 * i], sy = start_xy[2 * i + 1], gx = goal_xy[2 * i], gy = goal_xy[2 * i + 1];
+    if (sx < 0 || sx >= W || sy < 0 || sy >= H || gx < 0 || gx >= W || gy < 0 || gy >= H)
+      return fail(e, TS_E_INVALID, "vehicle start/goal out of bounds");
+    if (sx == gx && sy == gy) return fail(e, TS_E_UNSUPPORTED, "start == goal (vehicle despawns inside the decide phase)");
+    start[i] = sy * W + sx; goal[i] = gy * W + gx;
+    pop[i] = population_type ? population_type[i] : TS_POP_UNDEFINED;
+    int len = path_off[i + 1] - path_off[i];
+    if (len < 0) return fail(e, TS_E_INVALID, "path_off must be non-decreasing");
+    plen[i] = len;
+    poff[i] = (uint32_t)(e->pool_used + wpos);
+    int px = sx, py = sy;
+    for (int k = 0; k < len; k++) {
+      int x = path_xy[2 * (path_off[i] + k)], y = path_xy[2 * (path_off[i] + k) + 1];
+      int dx = x - px, dy = y - py, dir;
+      if (dx == 0 && dy == 1) dir = 0; else if (dx == 1 && dy == 0) dir = 1;
+      else if (dx == 0 && dy == -1) dir = 2; else if (dx == -1 && dy == 0) dir = 3;
+      else return fail(e, TS_E_INVALID, "explicit path is not a 4-adjacent chain");
+      if (x < 0 || x >= W || y < 0 || y >= H) return fail(e, TS_E_INVALID, "explicit path leaves the grid");
+      enc[wpos + (k >> 4)] |= (uint32_t)dir << ((k & 15) * 2);
+      px = x; py = y;
+    }
+    wpos += ((size_t)len + 15) / 16;
+  }
+  // start cells shared inside the batch must be appended to the cell list in spawn order
+  std::vector<uint8_t> serial(n, 0);
+  {
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return start[a] < start[b] || (start[a] == start[b] && a < b); });
+    for (int q = 1; q < n; q++)
+      if (start[order[q]] == start[order[q - 1]]) { serial[order[q]] = 1; serial[order[q - 1]] = 1; }
+  }
+  int rc = ensure_vehicle_capacity(e, e->n_vehicles_total + n, e->n_sched + n);
+  if (rc) return rc;
+  rc = ensure_pool(e, e->pool_used + words + 1);
+  if (rc) return rc;
+  if (n > e->cap_overflow) {
+    rc = regrow(e, &e->d_overflow, 0, (size_t)n + 1);
+    if (rc) return rc;
+    e->cap_overflow = n;
+  }
+  hipStream_t st = e->stream;
+  int32_t *ds = nullptr, *dg = nullptr, *dp = nullptr, *dl = nullptr;
+  uint32_t* dof = nullptr;
+  uint8_t* dser = nullptr;
+  HIPOK(hipMalloc((void**)&ds, (size_t)n * 4)); HIPOK(hipMalloc((void**)&dg, (size_t)n * 4));
+  HIPOK(hipMalloc((void**)&dp, (size_t)n * 4)); HIPOK(hipMalloc((void**)&dl, (size_t)n * 4));
+  HIPOK(hipMalloc((void**)&dof, (size_t)n * 4)); HIPOK(hipMalloc((void**)&dser, (size_t)n));
+  HIPOK(hipMemcpyAsync(ds, start.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPOK(hipMemcpyAsync(dg, goal.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPOK(hipMemcpyAsync(dp, pop.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPOK(hipMemcpyAsync(dl, plen.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPOK(hipMemcpyAsync(dof, poff.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPOK(hipMemcpyAsync(dser, serial.data(), (size_t)n, hipMemcpyHostToDevice, st));
+  if (words) HIPOK(hipMemcpyAsync(e->d.pool + e->pool_used, enc.data(), words * 4, hipMemcpyHostToDevice, st));
+  HIPOK(hipMemsetAsync(e->d_total, 0, sizeof(int), st));
+  SpawnArgs a{ds, dg, dp, dl, dof, dser};
+  hipLaunchKernelGGL(k_spawn, dim3(nblk(n)), dim3(BLK), 0, st, e->d, e->P, a, n, e->n_vehicles_total, e->n_active,
+                     e->n_sched, e->C.elapsed, e->d_overflow, e->d_total);
+  HIPOK(hipMemcpyAsync(e->hint, e->d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPOK(hipStreamSynchronize(st));
+  if (e->hint[0] > 0) hipLaunchKernelGGL(k_spawn_serial, dim3(1), dim3(64), 0, st, e->d, e->d_overflow, e->hint[0]);
+  HIPOK(hipStreamSynchronize(st));
+  (void)hipFree(ds); (void)hipFree(dg); (void)hipFree(dp); (void)hipFree(dl); (void)hipFree(dof); (void)hipFree(dser);
+  // live_* counters (city_model.py:1910-1918)
+  long long add_int = 0, add_thr = 0;
+  for (int i = 0; i < n; i++) { add_int += pop[i] == TS_POP_INTERNAL; add_thr += pop[i] == TS_POP_THROUGH; }
+  if (add_int || add_thr) {
+    rc = sync_counters(e);
+    if (rc) return rc;
+    e->hcnt->live_internal += add_int; e->hcnt->live_through += add_thr;
+    HIPOK(hipMemcpy(e->d.cnt, e->hcnt, sizeof(DevCnt), hipMemcpyHostToDevice));
+  }
+  e->pool_used += words;
+  e->n_vehicles_total += n; e->n_active += n; e->n_sched += n; e->n_sched_vehicles += n;
+  return TS_OK;
+}
+
+int ts_upload_map(ts_handle e, int32_t which, const int8_t* src) {
+  if (!e || !src) return TS_E_INVALID;
+  int8_t* m = which == TS_MAP_STOP ? e->d.stop : which == TS_MAP_RAIN ? e->d.rain : nullptr;
+  if (!m) return fail(e, TS_E_INVALID, "only stop_map and rain_map are host-writable");
+  HIPOK(hipMemcpy(m, src, e->N, hipMemcpyHostToDevice));
+  return TS_OK;
+}
+int ts_debug_set_occupancy(ts_handle e, const int8_t* src) {
+  if (!e || !src) return TS_E_INVALID;
+  HIPOK(hipMemcpy(e->d.occ, src, e->N, hipMemcpyHostToDevice));
+  return TS_OK;
+}
+
+int ts_step(ts_handle e, int32_t n_ticks) {
+  if (!e || n_ticks < 0) return TS_E_INVALID;
+  if (!e->seeded[0] || !e->seeded[1]) return fail(e, TS_E_STATE, "both RNG streams must be seeded before step");
+  if (e->groups_scheduled != e->d.G && e->d.G > 0 && e->groups_scheduled != 0)
+    return fail(e, TS_E_STATE, "every light group must be scheduled (or none)");
+  for (int t = 0; t < n_ticks; t++) {
+    int rc = tick(e);
+    if (rc) return rc;
+  }
+  return TS_OK;
+}
+
+int ts_num_vehicles(ts_handle e) { return e ? e->n_active : TS_E_INVALID; }
+int ts_num_groups(ts_handle e) { return e ? e->d.G : TS_E_INVALID; }
+int ts_num_scheduled(ts_handle e) { return e ? e->n_sched : TS_E_INVALID; }
+
+int ts_download_map(ts_handle e, int32_t which, int8_t* dst) {
+  if (!e || !dst) return TS_E_INVALID;
+  const int8_t* m = which == TS_MAP_OCCUPANCY ? e->d.occ : which == TS_MAP_STOP ? e->d.stop
+                   : which == TS_MAP_STUCK ? e->d.stuck : which == TS_MAP_RAIN ? e->d.rain : nullptr;
+  if (!m) return TS_E_INVALID;
+  HIPOK(hipMemcpy(dst, m, e->N, hipMemcpyDeviceToHost));
+  return TS_OK;
+}
+
+int ts_download_density(ts_handle e, float* dst) {
+  if (!e || !dst) return TS_E_INVALID;
+  float *t0 = nullptr, *t1 = nullptr, *dn = nullptr;
+  size_t N = e->N;
+  HIPOK(hipMalloc((void**)&t0, N * 4)); HIPOK(hipMalloc((void**)&t1, N * 4)); HIPOK(hipMalloc((void**)&dn, N * 4));
+  const int r = e->P.vehicle_awareness_range;
+  hipLaunchKernelGGL(k_density_pass0, dim3(nblk(N)), dim3(BLK), 0, e->stream, e->d.occ, e->d.is_road, e->W, e->H, r, t0, t1);
+  hipLaunchKernelGGL(k_density_pass1, dim3(nblk(N)), dim3(BLK), 0, e->stream, t0, t1, e->W, e->H, r, dn);
+  HIPOK(hipMemcpyAsync(dst, dn, N * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  (void)hipFree(t0); (void)hipFree(t1); (void)hipFree(dn);
+  return TS_OK;
+}
+
+int ts_download_vehicles(ts_handle e, int32_t* rows, int32_t cap_rows) {
+  if (!e || !rows) return TS_E_INVALID;
+  int n = e->n_active;
+  if (n > cap_rows) return TS_E_CAPACITY;
+  if (n == 0) return 0;
+  int32_t* drows = nullptr;
+  HIPOK(hipMalloc((void**)&drows, (size_t)n * TS_V_NFIELDS * 4));
+  hipLaunchKernelGGL(k_rows, dim3(nblk(n)), dim3(BLK), 0, e->stream, e->d, n, e->d_crc, drows);
+  HIPOK(hipMemcpyAsync(rows, drows, (size_t)n * TS_V_NFIELDS * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  (void)hipFree(drows);
+  return n;
+}
+
+int ts_download_path(ts_handle e, int32_t active_pos, int32_t* xy, int32_t cap_cells) {
+  if (!e || active_pos < 0 || active_pos >= e->n_active) return TS_E_INVALID;
+  int vid, cur, len;
+  HIPOK(hipMemcpy(&vid, e->d.active + active_pos, 4, hipMemcpyDeviceToHost));
+  HIPOK(hipMemcpy(&cur, e->d.path_cur + vid, 4, hipMemcpyDeviceToHost));
+  HIPOK(hipMemcpy(&len, e->d.path_len + vid, 4, hipMemcpyDeviceToHost));
+  int n = len - cur;
+  if (!xy) return n;
+  if (n > cap_cells) return TS_E_CAPACITY;
+  if (n == 0) return 0;
+  int32_t* dxy = nullptr;
+  HIPOK(hipMalloc((void**)&dxy, (size_t)n * 8));
+  hipLaunchKernelGGL(k_path_cells, dim3(1), dim3(64), 0, e->stream, e->d, vid, dxy);
+  HIPOK(hipMemcpyAsync(xy, dxy, (size_t)n * 8, hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  (void)hipFree(dxy);
+  return n;
+}
+
+int ts_download_groups(ts_handle e, int32_t* rows) {
+  if (!e || !rows) return TS_E_INVALID;
+  int G = e->d.G;
+  if (G == 0) return 0;
+  int32_t* drows = nullptr;
+  HIPOK(hipMalloc((void**)&drows, (size_t)G * TS_G_NFIELDS * 4));
+  hipLaunchKernelGGL(k_group_rows, dim3(nblk(G)), dim3(BLK), 0, e->stream, e->d, drows);
+  HIPOK(hipMemcpyAsync(rows, drows, (size_t)G * TS_G_NFIELDS * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  (void)hipFree(drows);
+  return G;
+}
+
+int ts_counters(ts_handle e, TsCounters* out) {
+  if (!e || !out) return TS_E_INVALID;
+  int rc = sync_counters(e);
+  if (rc) return rc;
+  *out = e->C;
+  return TS_OK;
+}
+
+int ts_astar(ts_handle e, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t*, int32_t) {
+  return fail(e, TS_E_UNSUPPORTED, "GPU A* is not built yet");
+}
+
+}  // extern "C"
