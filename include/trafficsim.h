@@ -241,6 +241,12 @@ int ts_rng_state(ts_handle h, int32_t stream, uint32_t* mt_out, uint32_t* index_
 int ts_add_vehicles(ts_handle h, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
                     const int32_t* population_type, const int32_t* path_off, const int32_t* path_xy);
 
+/* Same as ts_add_vehicles with the initial paths given as direction codes (N0 E1 S2 W3), one byte
+ * per step: vehicle i's path is path_dirs[path_off[i] .. path_off[i+1]).  An engine-side extension
+ * (the reference has no such entry) so that 10^6 synthetic routes do not travel as 8-byte (x, y) pairs. */
+int ts_add_vehicles_dirs(ts_handle h, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
+                         const int32_t* population_type, const int64_t* path_off, const uint8_t* path_dirs);
+
 /* Host writes between ticks (UI handlers / RainManager): whole-map upload of stop_map or
  * rain_map (cell.py:241-251, rain.py:156-184). */
 int ts_upload_map(ts_handle h, int32_t which, const int8_t* src);
@@ -265,6 +271,19 @@ int ts_counters(ts_handle h, TsCounters* out);
  * evaluated on the engine's current maps.  Returns the path length (0 = no path) or <0. */
 int ts_astar(ts_handle h, int32_t sx, int32_t sy, int32_t gx, int32_t gy, int32_t soft_obstacles,
              int32_t ignore_flow, int32_t maximum_steps, int32_t* out_xy, int32_t cap_cells);
+
+/* Select the HIP device used by subsequent ts_create calls in this process (one process per GPU:
+ * rank r of a multi-GPU launch calls ts_set_device(LOCAL_RANK)). */
+int ts_set_device(int32_t device);
+
+/* Per-kernel timing with HIP events recorded on the engine's own stream (bench.py's roofline leg).
+ * ts_profile_enable(h, 1) starts collecting; ts_profile_get returns, for kernel class `kernel_id`
+ * (0 <= id < ts_profile_count()), the summed device time in ms, the number of launches and the
+ * number of work items (agents / cells) those launches covered. */
+int ts_profile_enable(ts_handle h, int32_t on);
+int ts_profile_count(void);
+const char* ts_profile_name(int32_t kernel_id);
+int ts_profile_get(ts_handle h, int32_t kernel_id, double* total_ms, int64_t* launches, int64_t* items);
 
 /* Test hook: overwrite occupancy_map without placing vehicles (A* / density known-answer tests). */
 int ts_debug_set_occupancy(ts_handle h, const int8_t* src);

@@ -1136,6 +1136,29 @@ int tso_add_vehicles(ts_handle e, int32_t n, const int32_t* start_xy, const int3
   return TS_OK;
 }
 
+int tso_add_vehicles_dirs(ts_handle e, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
+                          const int32_t* population_type, const int64_t* path_off, const uint8_t* path_dirs) {
+  if (!e || n < 0 || !path_off || !path_dirs) return TS_E_INVALID;
+  // expand to (x, y) chains vehicle by vehicle and reuse the plain entry (keeps memory bounded)
+  std::vector<int32_t> xy;
+  for (int i = 0; i < n; i++) {
+    long long len = path_off[i + 1] - path_off[i];
+    xy.resize((size_t)len * 2);
+    int x = start_xy[2 * i], y = start_xy[2 * i + 1];
+    for (long long k = 0; k < len; k++) {
+      int d = path_dirs[path_off[i] + k];
+      if (d > 3) return fail(e, TS_E_INVALID, "direction code out of range");
+      x += DX[d]; y += DY[d];
+      xy[2 * k] = x; xy[2 * k + 1] = y;
+    }
+    int32_t off[2] = {0, (int32_t)len};
+    int rc = tso_add_vehicles(e, 1, start_xy + 2 * i, goal_xy + 2 * i, population_type ? population_type + i : nullptr,
+                              off, xy.data());
+    if (rc) return rc;
+  }
+  return TS_OK;
+}
+
 int tso_upload_map(ts_handle e, int32_t which, const int8_t* src) {
   if (!e || !src) return TS_E_INVALID;
   std::vector<int8_t>* m = which == TS_MAP_STOP ? &e->stop : which == TS_MAP_RAIN ? &e->rain : nullptr;
@@ -1263,6 +1286,12 @@ int tso_astar(ts_handle e, int32_t sx, int32_t sy, int32_t gx, int32_t gy, int32
   for (size_t i = 0; i < p.size(); i++) { out_xy[2 * i] = p[i] % e->W; out_xy[2 * i + 1] = p[i] / e->W; }
   return (int)p.size();
 }
+
+int tso_set_device(int32_t) { return TS_OK; }
+int tso_profile_enable(ts_handle, int32_t) { return TS_OK; }
+int tso_profile_count(void) { return 0; }
+const char* tso_profile_name(int32_t) { return ""; }
+int tso_profile_get(ts_handle, int32_t, double*, int64_t*, int64_t*) { return TS_E_INVALID; }
 
 /* test hook: write occupancy directly (A* KATs need an arbitrary occupancy map) */
 int tso_debug_set_occupancy(ts_handle e, const int8_t* src) {

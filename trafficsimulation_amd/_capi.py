@@ -160,6 +160,7 @@ class CApi:
         f("seed_int").argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
         f("rng_state").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_uint32)]
         f("add_vehicles").argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
+        f("add_vehicles_dirs").argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
         f("upload_map").argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         f("step").argtypes = [C.c_void_p, C.c_int32]
         f("download_map").argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -170,6 +171,12 @@ class CApi:
         f("counters").argtypes = [C.c_void_p, C.POINTER(TsCounters)]
         f("astar").argtypes = [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p, C.c_int32]
         f("debug_set_occupancy").argtypes = [C.c_void_p, C.c_void_p]
+        f("set_device").argtypes = [C.c_int32]
+        f("profile_enable").argtypes = [C.c_void_p, C.c_int32]
+        f("profile_name").restype = C.c_char_p
+        f("profile_name").argtypes = [C.c_int32]
+        f("profile_get").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64)]
 
     def _f(self, name):
         return getattr(self.lib, self.prefix + name)
@@ -284,10 +291,38 @@ class CApi:
             self.h, n, s.ctypes.data, g.ctypes.data, pt.ctypes.data,
             po.ctypes.data if po is not None else None, px.ctypes.data if px is not None else None))
 
+    def add_vehicles_dirs(self, start_xy, goal_xy, population_type, path_off, path_dirs):
+        """Routes as direction codes (N0 E1 S2 W3), one byte per step; path_off is int64."""
+        s, g = _i32(start_xy).reshape(-1, 2), _i32(goal_xy).reshape(-1, 2)
+        n = len(s)
+        pt = _i32(population_type if population_type is not None else np.zeros(n))
+        po = np.ascontiguousarray(path_off, dtype=np.int64)
+        pd = np.ascontiguousarray(path_dirs, dtype=np.uint8)
+        assert len(po) == n + 1 and len(pd) == po[-1]
+        self._chk(self._f("add_vehicles_dirs")(self.h, n, s.ctypes.data, g.ctypes.data, pt.ctypes.data,
+                                                po.ctypes.data, pd.ctypes.data))
+
     def upload_map(self, which: int, arr):
         a = np.ascontiguousarray(arr, dtype=np.int8)
         assert a.shape == (self.H, self.W)
         self._chk(self._f("upload_map")(self.h, which, a.ctypes.data))
+
+    def set_device(self, device: int):
+        rc = self._f("set_device")(device)
+        if rc < 0:
+            raise EngineError(rc, f"cannot select HIP device {device}")
+
+    def profile_enable(self, on: bool = True):
+        self._chk(self._f("profile_enable")(self.h, int(on)))
+
+    def profile(self) -> dict:
+        """{kernel name: (total_ms, launches, items)} measured with HIP events on the engine's stream."""
+        out = {}
+        for k in range(self._f("profile_count")()):
+            ms, n, it = C.c_double(), C.c_int64(), C.c_int64()
+            self._chk(self._f("profile_get")(self.h, k, C.byref(ms), C.byref(n), C.byref(it)))
+            out[self._f("profile_name")(k).decode()] = (ms.value, n.value, it.value)
+        return out
 
     def debug_set_occupancy(self, arr):
         """Test hook: overwrite occupancy_map without placing vehicles (A*/density KATs)."""

@@ -113,24 +113,15 @@ __global__ void k_decide_pre(Dev d, TsParams P, int start, int n_active) {
   int i = start + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_active) return;
   int vid = d.active[i];
-  if (vid < 0) { d.F[i] = 0; return; }
-  uint16_t f = d.flags[vid];
-  bool sb = (f & (VF_COLL | VF_MALF)) != 0;
-  bool sa = sb && (d.stranded_left[vid] - 1 > 0);
-  if (!P.malfunction_active) sa = true;  // `not ACTIVE or ...`: every vehicle malfunctions (vehicle_base.py:609)
-  d.st_before[vid] = sb;
-  d.st_after[vid] = sa;
-}
-__global__ void k_decide_pre2(Dev d, TsParams P, int start, int n_active) {
-  int i = start + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_active) return;
-  int vid = d.active[i];
   uint8_t F = 0;
   int cand = -1;
   if (vid >= 0) {
     uint16_t f = d.flags[vid];
     bool sb = (f & (VF_COLL | VF_MALF)) != 0;
     bool still = sb && (d.stranded_left[vid] - 1 > 0);
+    // strandedness before / after this vehicle's own step_decide, for k_decide_main's blocker checks
+    d.st_before[vid] = sb;
+    d.st_after[vid] = still || !P.malfunction_active;  // `not ACTIVE or ...`: everyone malfunctions (609)
     if (!still && P.malfunction_active) {
       F |= F_DRAW_MALF;
       const int W = d.W, H = d.H;
@@ -146,7 +137,8 @@ __global__ void k_decide_pre2(Dev d, TsParams P, int start, int n_active) {
           for (int ag = d.cell_veh[ny * W + nx]; ag >= 0; ag = d.next_in_cell[ag]) {
             uint16_t af = d.flags[ag];
             bool earlier = d.active_idx[ag] < i;
-            bool ag_str = earlier ? (d.ev[ag] ? true : d.st_after[ag] != 0) : (d.st_before[ag] != 0);
+            bool ag_sb = (af & (VF_COLL | VF_MALF)) != 0;
+            bool ag_str = earlier ? (d.ev[ag] ? true : ((ag_sb && d.stranded_left[ag] - 1 > 0) || !P.malfunction_active)) : ag_sb;
             bool cs_pos = earlier ? (!ag_str && d.stop[d.pos[ag]] != 1) : (d.cur_speed[ag] > 0);
             if (!cs_pos || (af & (VF_STUCK | VF_PARKED)) || ag_str) continue;
             if (d.dir[ag] != opposite) continue;
@@ -854,11 +846,52 @@ struct ts_engine {
   TsCounters C;
   std::vector<uint32_t> perm;
   std::vector<void*> allocs;
+  // per-kernel HIP-event timing (ts_profile_*)
+  bool prof = false;
+  std::vector<hipEvent_t> ev_pool;
+  struct ProfRec { int id; int e0, e1; long long items; };
+  std::vector<ProfRec> prof_pending;
+  size_t ev_used = 0;
+  double prof_ms[8] = {0};
+  long long prof_launches[8] = {0}, prof_items[8] = {0};
 };
 
 namespace {
 
 typedef ts_engine E;
+
+enum { PK_DECIDE_PRE = 0, PK_DECIDE_MAIN, PK_MOVE_CLAIM, PK_MOVE_RESOLVE, PK_COMPACT, PK_EVENT, PK_COUNT };
+const char* PK_NAMES[PK_COUNT] = {"k_decide_pre", "k_decide_main", "k_move_claim", "k_move_resolve",
+                                  "k_compact", "k_apply_event"};
+
+int prof_begin(E* e, int id, long long items) {
+  if (!e->prof) return -1;
+  if (e->ev_used + 2 > e->ev_pool.size()) {
+    for (int k = 0; k < 64; k++) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return -1; e->ev_pool.push_back(ev); }
+  }
+  int a = (int)e->ev_used, b = a + 1;
+  e->ev_used += 2;
+  (void)hipEventRecord(e->ev_pool[a], e->stream);
+  e->prof_pending.push_back({id, a, b, items});
+  return b;
+}
+inline void prof_end(E* e, int tok) { if (tok >= 0) (void)hipEventRecord(e->ev_pool[tok], e->stream); }
+void prof_collect(E* e) {  // call after a stream synchronize
+  for (auto& r : e->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev_pool[r.e0], e->ev_pool[r.e1]) == hipSuccess) {
+      e->prof_ms[r.id] += ms; e->prof_launches[r.id]++; e->prof_items[r.id] += r.items;
+    }
+  }
+  e->prof_pending.clear();
+  e->ev_used = 0;
+}
+#define LAUNCH(e, id, items, kernel, grid, block, ...)                                   \
+  do {                                                                                   \
+    int _tok = prof_begin((e), (id), (items));                                           \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (e)->stream, __VA_ARGS__);                \
+    prof_end((e), _tok);                                                                 \
+  } while (0)
 
 int fail(E* e, int code, const std::string& msg) {
   if (e) e->err = msg;
@@ -970,10 +1003,12 @@ int compact(E* e, int which, int n, int* out_n) {
   Dev& d = e->d;
   int nb = nblk(n, BLK * CITEMS);
   if (n == 0) { *out_n = 0; return TS_OK; }
+  int _tok = prof_begin(e, PK_COMPACT, n);
   hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(BLK), 0, e->stream, d.active, d.sched_kind, n, which, e->block_counts);
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, e->block_counts, nb, e->d_total);
   hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(BLK), 0, e->stream, d, n, which, e->block_counts, e->active_alt,
                      e->kind_alt, e->ref_alt);
+  prof_end(e, _tok);
   HIPOK(hipMemcpyAsync(e->hint, e->d_total, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIPOK(hipStreamSynchronize(e->stream));
   *out_n = e->hint[0];
@@ -1013,8 +1048,7 @@ int tick(E* e) {
     while (true) {
       int cnt = nA - start;
       if (cnt > 0) {
-        hipLaunchKernelGGL(k_decide_pre, dim3(nblk(cnt)), dim3(BLK), 0, st, d, P, start, nA);
-        hipLaunchKernelGGL(k_decide_pre2, dim3(nblk(cnt)), dim3(BLK), 0, st, d, P, start, nA);
+        LAUNCH(e, PK_DECIDE_PRE, cnt, k_decide_pre, dim3(nblk(cnt)), dim3(BLK), d, P, start, nA);
         HIPOK(hipMemcpyAsync(e->hF + start, d.F + start, cnt, hipMemcpyDeviceToHost, st));
       }
       HIPOK(hipStreamSynchronize(st));
@@ -1042,12 +1076,12 @@ int tick(E* e) {
       HIPOK(hipMemcpyAsync(&e->hint[1], d.cand + ev_at, sizeof(int), hipMemcpyDeviceToHost, st));
       HIPOK(hipStreamSynchronize(st));
       ids[0] = e->hint[0]; ids[1] = e->hint[1];
-      hipLaunchKernelGGL(k_apply_event, dim3(1), dim3(64), 0, st, d, P, ids[0], ev_coll, ids[1], ev_at);
+      LAUNCH(e, PK_EVENT, 1, k_apply_event, dim3(1), dim3(64), d, P, ids[0], ev_coll, ids[1], ev_at);
       i = ev_at + 1;
       start = i;
     }
     HIPOK(hipMemcpyAsync(d.R, e->hR, nA, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_decide_main, dim3(nblk(nA)), dim3(BLK), 0, st, d, P, nA);
+    LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA);
   }
 
   // ---------------- move (schedule.step) ----------------
@@ -1071,8 +1105,8 @@ int tick(E* e) {
         }
         const uint32_t prefix = (EPOCHS - 1) - (e->epoch % EPOCHS);
         e->epoch++;
-        hipLaunchKernelGGL(k_move_claim, dim3(nblk(nS)), dim3(BLK), 0, st, d, P, nS, prefix);
-        hipLaunchKernelGGL(k_move_resolve, dim3(nblk(nS)), dim3(BLK), 0, st, d, P, nS, prefix, rank_clock, elapsed0);
+        LAUNCH(e, PK_MOVE_CLAIM, nS, k_move_claim, dim3(nblk(nS)), dim3(BLK), d, P, nS, prefix);
+        LAUNCH(e, PK_MOVE_RESOLVE, nS, k_move_resolve, dim3(nblk(nS)), dim3(BLK), d, P, nS, prefix, rank_clock, elapsed0);
         e->C.move_rounds++;
       }
       HIPOK(hipMemcpyAsync(e->hint, &d.cnt->resolved, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
@@ -1102,11 +1136,13 @@ int tick(E* e) {
   }
   if (e->clock_slot >= 0) e->C.elapsed += P.time_per_step_seconds;
   e->C.step_count++;
+  if (e->prof) { HIPOK(hipStreamSynchronize(st)); prof_collect(e); }
   return TS_OK;
 }
 
 }  // namespace
 
+static int g_device = 0;  // ts_set_device
 extern "C" {
 
 void ts_default_params(TsParams* p) {
@@ -1137,6 +1173,7 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
     return TS_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return TS_E_DEVICE;
+  if (hipSetDevice(g_device) != hipSuccess) return TS_E_DEVICE;
   E* e = new E();
   memset(&e->d, 0, sizeof(e->d));
   memset(&e->C, 0, sizeof(e->C));
@@ -1186,6 +1223,7 @@ int ts_destroy(ts_handle e) {
   if (!e) return TS_OK;
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (void* p : e->allocs) (void)hipFree(p);
+  for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->hF) (void)hipHostFree(e->hF);
   if (e->hR) (void)hipHostFree(e->hR);
   if (e->hrank) (void)hipHostFree(e->hrank);
@@ -1317,45 +1355,13 @@ int ts_rng_state(ts_handle e, int32_t stream, uint32_t* mt_out, uint32_t* index_
   return TS_OK;
 }
 
-int ts_add_vehicles(ts_handle e, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
-                    const int32_t* population_type, const int32_t* path_off, const int32_t* path_xy) {
-  if (!e || n < 0 || (n > 0 && (!start_xy || !goal_xy))) return TS_E_INVALID;
-  if (n == 0) return TS_OK;
-  if (!path_off || !path_xy)
-    return fail(e, TS_E_UNSUPPORTED, "initial paths must be supplied until the GPU A* is built");
-  const int W = e->W, H = e->H;
-  if ((long long)e->n_sched + n >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
-  std::vector<int32_t> start(n), goal(n), pop(n), plen(n);
-  std::vector<uint32_t> poff(n);
-  // encode paths as 2-bit directions; every vehicle starts on a fresh 32-bit word
-  size_t words = 0;
-  for (int i = 0; i < n; i++) words += ((size_t)(path_off[i + 1] - path_off[i]) + 15) / 16;
-  std::vector<uint32_t> enc(words, 0);
-  size_t wpos = 0;
-  for (int i = 0; i < n; i++) {
-    int sx = start_xy[2 * i], sy = start_xy[2 * i + 1], gx = goal_xy[2 * i], gy = goal_xy[2 * i + 1];
-    if (sx < 0 || sx >= W || sy < 0 || sy >= H || gx < 0 || gx >= W || gy < 0 || gy >= H)
-      return fail(e, TS_E_INVALID, "vehicle start/goal out of bounds");
-    if (sx == gx && sy == gy) return fail(e, TS_E_UNSUPPORTED, "start == goal (vehicle despawns inside the decide phase)");
-    start[i] = sy * W + sx; goal[i] = gy * W + gx;
-    pop[i] = population_type ? population_type[i] : TS_POP_UNDEFINED;
-    int len = path_off[i + 1] - path_off[i];
-    if (len < 0) return fail(e, TS_E_INVALID, "path_off must be non-decreasing");
-    plen[i] = len;
-    poff[i] = (uint32_t)(e->pool_used + wpos);
-    int px = sx, py = sy;
-    for (int k = 0; k < len; k++) {
-      int x = path_xy[2 * (path_off[i] + k)], y = path_xy[2 * (path_off[i] + k) + 1];
-      int dx = x - px, dy = y - py, dir;
-      if (dx == 0 && dy == 1) dir = 0; else if (dx == 1 && dy == 0) dir = 1;
-      else if (dx == 0 && dy == -1) dir = 2; else if (dx == -1 && dy == 0) dir = 3;
-      else return fail(e, TS_E_INVALID, "explicit path is not a 4-adjacent chain");
-      if (x < 0 || x >= W || y < 0 || y >= H) return fail(e, TS_E_INVALID, "explicit path leaves the grid");
-      enc[wpos + (k >> 4)] |= (uint32_t)dir << ((k & 15) * 2);
-      px = x; py = y;
-    }
-    wpos += ((size_t)len + 15) / 16;
-  }
+// shared tail of the two ts_add_vehicles entries: `enc` holds the 2-bit direction words, every
+// vehicle starting on a fresh word; poff[i] is relative to enc.
+static int add_vehicles_core(ts_handle e, int n, std::vector<int32_t>& start, std::vector<int32_t>& goal,
+                             std::vector<int32_t>& pop, std::vector<int32_t>& plen, std::vector<uint32_t>& poff,
+                             std::vector<uint32_t>& enc) {
+  const size_t words = enc.size();
+  for (int i = 0; i < n; i++) poff[i] += (uint32_t)e->pool_used;
   // start cells shared inside the batch must be appended to the cell list in spawn order
   std::vector<uint8_t> serial(n, 0);
   {
@@ -1409,6 +1415,70 @@ int ts_add_vehicles(ts_handle e, int32_t n, const int32_t* start_xy, const int32
   e->pool_used += words;
   e->n_vehicles_total += n; e->n_active += n; e->n_sched += n; e->n_sched_vehicles += n;
   return TS_OK;
+}
+
+static int add_vehicles_any(ts_handle e, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
+                            const int32_t* population_type, const int32_t* off32, const int32_t* path_xy,
+                            const int64_t* off64, const uint8_t* path_dirs) {
+  if (!e || n < 0 || (n > 0 && (!start_xy || !goal_xy))) return TS_E_INVALID;
+  if (n == 0) return TS_OK;
+  if (!(off32 && path_xy) && !(off64 && path_dirs))
+    return fail(e, TS_E_UNSUPPORTED, "initial paths must be supplied until the GPU A* is built");
+  const int W = e->W, H = e->H;
+  if ((long long)e->n_sched + n >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
+  std::vector<int32_t> start(n), goal(n), pop(n), plen(n);
+  std::vector<uint32_t> poff(n);
+  auto O = [&](int i) -> long long { return off32 ? (long long)off32[i] : (long long)off64[i]; };
+  size_t words = 0;
+  for (int i = 0; i < n; i++) {
+    long long len = O(i + 1) - O(i);
+    if (len < 0 || len > 0x7FFFFFFF) return fail(e, TS_E_INVALID, "path_off must be non-decreasing");
+    words += ((size_t)len + 15) / 16;
+  }
+  if (e->pool_used + words >= (1ull << 32)) return fail(e, TS_E_CAPACITY, "path pool exceeds 2^32 words");
+  std::vector<uint32_t> enc(words, 0);
+  size_t wpos = 0;
+  for (int i = 0; i < n; i++) {
+    int sx = start_xy[2 * i], sy = start_xy[2 * i + 1], gx = goal_xy[2 * i], gy = goal_xy[2 * i + 1];
+    if (sx < 0 || sx >= W || sy < 0 || sy >= H || gx < 0 || gx >= W || gy < 0 || gy >= H)
+      return fail(e, TS_E_INVALID, "vehicle start/goal out of bounds");
+    if (sx == gx && sy == gy) return fail(e, TS_E_UNSUPPORTED, "start == goal (vehicle despawns inside the decide phase)");
+    start[i] = sy * W + sx; goal[i] = gy * W + gx;
+    pop[i] = population_type ? population_type[i] : TS_POP_UNDEFINED;
+    const long long o = O(i);
+    const int len = (int)(O(i + 1) - o);
+    plen[i] = len;
+    poff[i] = (uint32_t)wpos;
+    int px = sx, py = sy;
+    for (int k = 0; k < len; k++) {
+      int dir;
+      if (path_xy && off32) {
+        int x = path_xy[2 * (o + k)], y = path_xy[2 * (o + k) + 1];
+        int dx = x - px, dy = y - py;
+        if (dx == 0 && dy == 1) dir = 0; else if (dx == 1 && dy == 0) dir = 1;
+        else if (dx == 0 && dy == -1) dir = 2; else if (dx == -1 && dy == 0) dir = 3;
+        else return fail(e, TS_E_INVALID, "explicit path is not a 4-adjacent chain");
+        px = x; py = y;
+      } else {
+        dir = path_dirs[o + k];
+        if (dir > 3) return fail(e, TS_E_INVALID, "direction code out of range");
+        px += (dir == 1) - (dir == 3); py += (dir == 0) - (dir == 2);
+      }
+      if (px < 0 || px >= W || py < 0 || py >= H) return fail(e, TS_E_INVALID, "explicit path leaves the grid");
+      enc[wpos + (k >> 4)] |= (uint32_t)dir << ((k & 15) * 2);
+    }
+    wpos += ((size_t)len + 15) / 16;
+  }
+  return add_vehicles_core(e, n, start, goal, pop, plen, poff, enc);
+}
+
+int ts_add_vehicles(ts_handle e, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
+                    const int32_t* population_type, const int32_t* path_off, const int32_t* path_xy) {
+  return add_vehicles_any(e, n, start_xy, goal_xy, population_type, path_off, path_xy, nullptr, nullptr);
+}
+int ts_add_vehicles_dirs(ts_handle e, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
+                         const int32_t* population_type, const int64_t* path_off, const uint8_t* path_dirs) {
+  return add_vehicles_any(e, n, start_xy, goal_xy, population_type, nullptr, nullptr, path_off, path_dirs);
 }
 
 int ts_upload_map(ts_handle e, int32_t which, const int8_t* src) {
@@ -1514,6 +1584,29 @@ int ts_counters(ts_handle e, TsCounters* out) {
   int rc = sync_counters(e);
   if (rc) return rc;
   *out = e->C;
+  return TS_OK;
+}
+
+int ts_set_device(int32_t device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return TS_E_DEVICE;
+  g_device = device;
+  return hipSetDevice(device) == hipSuccess ? TS_OK : TS_E_DEVICE;
+}
+int ts_profile_enable(ts_handle e, int32_t on) {
+  if (!e) return TS_E_INVALID;
+  e->prof = on != 0;
+  if (on) { memset(e->prof_ms, 0, sizeof(e->prof_ms)); memset(e->prof_launches, 0, sizeof(e->prof_launches));
+            memset(e->prof_items, 0, sizeof(e->prof_items)); }
+  return TS_OK;
+}
+int ts_profile_count(void) { return PK_COUNT; }
+const char* ts_profile_name(int32_t id) { return id >= 0 && id < PK_COUNT ? PK_NAMES[id] : ""; }
+int ts_profile_get(ts_handle e, int32_t id, double* total_ms, int64_t* launches, int64_t* items) {
+  if (!e || id < 0 || id >= PK_COUNT) return TS_E_INVALID;
+  if (total_ms) *total_ms = e->prof_ms[id];
+  if (launches) *launches = e->prof_launches[id];
+  if (items) *items = e->prof_items[id];
   return TS_OK;
 }
 
