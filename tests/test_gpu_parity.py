@@ -7,7 +7,7 @@ import pytest
 
 from trafficsimulation_amd import _capi as capi
 from trafficsimulation_amd.world import load_trace
-from tests.trace_util import NO_ASTAR_TRACES, check_initial, replay_and_compare, setup_from_trace, trace_path
+from tests.trace_util import CLOSED_TRACES, check_initial, replay_and_compare, setup_from_trace, trace_path
 
 pytestmark = pytest.mark.gpu
 
@@ -20,13 +20,33 @@ def hip():
     api.close()
 
 
-@pytest.mark.parametrize("name", NO_ASTAR_TRACES)
+@pytest.mark.parametrize("name", CLOSED_TRACES)
 def test_hip_reproduces_reference_trace(hip, name):
+    """Every closed-population trace captured from the reference: car-following, the light controllers, the
+    full replanning policy (GPU A*, phases 0-4), frequent strandings, sub-block roads.  Vehicles are spawned
+    without paths, so the spawn-time planner (cache + A*) is part of the check."""
     tr = load_trace(trace_path(name))
-    setup_from_trace(hip, tr, explicit_paths=True)
+    setup_from_trace(hip, tr, explicit_paths=False)
     check_initial(hip, tr)
+    assert hip.counters().astar_calls == int(tr["astar_calls_spawn"])
     n = replay_and_compare(hip, tr)
     assert n == len(tr["veh_off"]) - 1
+    assert hip.counters().astar_calls == int(tr["astar_calls_spawn"]) + int(tr["astar_per_tick"].sum())
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_astar_kats(hip, golden_dir, tag):
+    """The pathfinder operator seam (ts_astar) against the reference's astar_numba on 260 queries per map:
+    strict / soft / contraflow / step-limited, failures included."""
+    k = np.load(os.path.join(golden_dir, "astar_kats.npz"))
+    hip.create(k[f"{tag}_allowed_dirs_map"], k[f"{tag}_is_road_map"], k[f"{tag}_road_type_map"],
+               k[f"{tag}_intersection_map"], hip.default_params())
+    hip.debug_set_occupancy(k[f"{tag}_occupancy_map"])
+    hip.upload_map(capi.MAP_STOP, k[f"{tag}_stop_map"])
+    q, off, xy = k[f"{tag}_queries"], k[f"{tag}_path_off"], k[f"{tag}_path_xy"]
+    for i, (sx, sy, gx, gy, soft, ign, maxs) in enumerate(q):
+        got = hip.astar(int(sx), int(sy), int(gx), int(gy), bool(soft), bool(ign), int(maxs))
+        assert np.array_equal(got, xy[off[i]:off[i + 1]]), f"query {i}: {q[i]}"
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
@@ -88,17 +108,32 @@ def test_hip_vs_oracle_lights_512():
     _compare(h, c, 60)
 
 
-def test_hip_faults_request_replan_loudly():
-    """Malfunctions and sideswipes made frequent: the host scan finds events (fix-up path), and the first
-    vehicle blocked by a stranded one asks for a replan - which must surface as TS_E_UNSUPPORTED until the
-    GPU A* exists, never as a silent CPU fallback."""
-    h, c = _pair(256, 3_000, 5, {"VEHICLE_SIDESWIPE_COLLISION_CHANCE": 0.3, "VEHICLE_SIDESWIPE_COLLISION_DURATION": 5,
-                                  "VEHICLE_MALFUNCTION_CHANCE": 0.002, "VEHICLE_MALFUNCTION_DURATION": 4,
-                                  "PATHFINDING_COOLDOWN": 10 ** 9})
-    with pytest.raises(capi.EngineError) as ei:
-        h.step(30)
-    assert ei.value.code == capi.TS_E_UNSUPPORTED
-    assert h.counters().rng_fixups > 0
+def test_hip_vs_oracle_full_policy_256():
+    """Defaults (queue-actuated lights, replans, contraflow) with strandings made frequent, on a synthetic
+    256x256 world: the host-scan fix-up path, blocker-triggered replans and overtakes all fire."""
+    pol = {"TRAFFIC_LIGHT_AGENT_ALGORITHM": "QUEUE_ACTUATED", "PATHFINDING_COOLDOWN": 5,
+           "VEHICLE_STUCK_RECOMPUTE_THRESHOLD": 30, "VEHICLE_STUCK_RECOMPUTE_THRESHOLD_INTERSECTION": 1,
+           "VEHICLE_CONTRAFLOW_OVERTAKE_ACTIVE": True, "VEHICLE_STUCK_CONTRAFLOW_ENABLED": True,
+           "VEHICLE_SIDESWIPE_COLLISION_CHANCE": 0.05, "VEHICLE_SIDESWIPE_COLLISION_DURATION": 30,
+           "VEHICLE_MALFUNCTION_CHANCE": 0.001, "VEHICLE_MALFUNCTION_DURATION": 25}
+    h, c = _pair(256, 2_000, 5, pol)
+    hc = None
+    for t in range(40):
+        h.step(1)
+        c.step(1)
+        a, b = h.vehicles(), c.vehicles()
+        assert a.shape == b.shape, f"tick {t}"
+        if not np.array_equal(a, b):
+            r, col = np.argwhere(a != b)[0]
+            raise AssertionError(f"tick {t}: vehicle row {r} field {capi.V_FIELDS[col]}: hip {a[r, col]} cpu {b[r, col]}")
+        assert np.array_equal(h.map(capi.MAP_OCCUPANCY), c.map(capi.MAP_OCCUPANCY)), f"tick {t}"
+        assert np.array_equal(h.map(capi.MAP_STOP), c.map(capi.MAP_STOP)), f"tick {t}"
+        assert h.rng_fingerprint(capi.RNG_GLOBAL) == c.rng_fingerprint(capi.RNG_GLOBAL), f"tick {t}: RNG"
+    hc, cc = h.counters(), c.counters()
+    assert hc.rng_fixups > 0 and hc.astar_calls == cc.astar_calls and hc.astar_calls > 100
+    assert (hc.astar_expansions, hc.astar_relaxations) == (cc.astar_expansions, cc.astar_relaxations)
+    assert (hc.overtaking, hc.in_stuck_detour, hc.collisions, hc.malfunctions) == (
+        cc.overtaking, cc.in_stuck_detour, cc.collisions, cc.malfunctions)
     h.close()
     c.close()
 

@@ -1,0 +1,678 @@
+// astar.h - GPU A* (one search per lane) and the replanning policy of VehicleAgent.
+//
+// astar_dev restates astar_numba.py:87-239 verbatim, quirks included:
+//   * binary heap keyed on f only, strict '<' in both sift routines (52-85);
+//   * dir_arr lives in heap-SLOT order and is NOT swapped by the sifts, so prev_dir = dir_arr[0] is a
+//     stale slot value (139, 147, 235);
+//   * `ng` is a double (R1 penalty 0.5) that truncates when stored into the int32 arrays (226-232);
+//   * soft-obstacle penalty int(1000 * (1 + 4 * density)) in double arithmetic on the float32 density.
+// Instead of the reference's O(W*H) per-call initialisation (119-122) every searcher owns an
+// epoch-stamped open-addressing table in HBM (dist / came_from by cell) and a private heap; a search
+// that outgrows its tier reports overflow and is re-run, unchanged, on a larger tier.
+//
+// decide_vehicle restates step_decide (vehicle_base.py:616-663) with _recompute_path_on_stuck 506-517,
+// _recompute_path_on_obstacle 454-504, _compute_path 143-167 and _compute_path_internal 199-420
+// (phases 0-4).  It is a pure function of the tick-start state until its final commit, so the same code
+// runs in k_decide_main (no scratch: bails out as soon as a search is needed) and in k_decide_replan.
+#pragma once
+#include "dev.h"
+
+namespace {
+
+constexpr int A_INF = 0x3F3F3F3F;
+constexpr int MAXB = 64;  // longest contraflow bypass (VEHICLE_MAX_CONTRAFLOW_*_STEPS <= 64)
+enum { DV_DONE = 0, DV_DEFER = 1, DV_OVERFLOW = 2, DV_POOL_FULL = 3 };
+
+// One searcher's scratch (all in HBM, carved from a tier arena).
+struct AScratch {
+  int32_t *hkey, *hdist, *hcame;
+  uint32_t* hstamp;
+  uint32_t hmask;
+  int32_t *hf, *hg, *hs, *hi;
+  int8_t* hd;
+  int heap_cap;
+  int32_t *A, *P, *T, *PO, *PD;  // cap cells each: A* result, current new path, splice target, staged pre-paths
+  int32_t *BYP, *OV, *DV;        // MAXB cells each: bypass result, staged overtake / detour paths
+  int cap;
+  uint32_t epoch;
+  int nodes;
+  long long calls, expansions, relaxations;
+};
+
+struct ATier {
+  int cap, n_slots, heap_cap;
+  uint32_t hsize;  // power of two >= 2 * cap
+  int32_t *hkey, *hdist, *hcame;
+  uint32_t* hstamp;
+  int32_t *hf, *hg, *hs, *hi;
+  int8_t* hd;
+  int32_t* cells;      // per slot: 5 * cap + 3 * MAXB
+  uint32_t* slot_epoch;
+};
+
+__device__ __forceinline__ void scratch_bind(const ATier& t, int slot, AScratch& S) {
+  size_t ho = (size_t)slot * t.hsize, po = (size_t)slot * t.heap_cap;
+  S.hkey = t.hkey + ho; S.hdist = t.hdist + ho; S.hcame = t.hcame + ho; S.hstamp = t.hstamp + ho;
+  S.hmask = t.hsize - 1;
+  S.hf = t.hf + po; S.hg = t.hg + po; S.hs = t.hs + po; S.hi = t.hi + po; S.hd = t.hd + po;
+  S.heap_cap = t.heap_cap;
+  int32_t* c = t.cells + (size_t)slot * ((size_t)5 * t.cap + 3 * MAXB);
+  S.A = c; S.P = c + t.cap; S.T = c + 2 * (size_t)t.cap; S.PO = c + 3 * (size_t)t.cap; S.PD = c + 4 * (size_t)t.cap;
+  S.BYP = c + 5 * (size_t)t.cap; S.OV = S.BYP + MAXB; S.DV = S.OV + MAXB;
+  S.cap = t.cap;
+  S.epoch = t.slot_epoch[slot];
+  S.nodes = 0; S.calls = 0; S.expansions = 0; S.relaxations = 0;
+}
+
+__device__ __forceinline__ uint32_t h_hash(int cell, uint32_t mask) { return ((uint32_t)cell * 2654435761u >> 7) & mask; }
+
+// returns slot of `cell`, or the empty slot where it would go (found = false)
+__device__ __forceinline__ uint32_t h_probe(const AScratch& S, int cell, bool& found) {
+  uint32_t h = h_hash(cell, S.hmask);
+  for (;;) {
+    if (S.hstamp[h] != S.epoch) { found = false; return h; }
+    if (S.hkey[h] == cell) { found = true; return h; }
+    h = (h + 1) & S.hmask;
+  }
+}
+__device__ __forceinline__ int h_dist(const AScratch& S, int cell) {
+  bool f;
+  uint32_t h = h_probe(S, cell, f);
+  return f ? S.hdist[h] : A_INF;
+}
+
+__device__ __forceinline__ void heap_swap(AScratch& S, int a, int b) {
+  int t;
+  t = S.hf[a]; S.hf[a] = S.hf[b]; S.hf[b] = t;
+  t = S.hg[a]; S.hg[a] = S.hg[b]; S.hg[b] = t;
+  t = S.hs[a]; S.hs[a] = S.hs[b]; S.hs[b] = t;
+  t = S.hi[a]; S.hi[a] = S.hi[b]; S.hi[b] = t;
+}
+
+// astar_core.  Writes the path (start excluded, goal included) to out[0..len); returns len >= 0, or -1 on
+// tier overflow (table, heap or output capacity).
+__device__ int astar_dev(const Dev& d, const TsParams& P, AScratch& S, int start_idx, int goal_idx, bool soft,
+                         bool ignore_flow, int maximum_steps, int32_t* out, int out_cap) {
+  const int W = d.W, H = d.H;
+  S.calls++;
+  S.epoch++;
+  if (S.epoch == 0) {  // stamp wrapped (once per 2^32 searches): clear the table
+    for (uint32_t q = 0; q <= S.hmask; q++) S.hstamp[q] = 0;
+    S.epoch = 1;
+  }
+  S.nodes = 0;
+  const int gx = goal_idx % W, gy = goal_idx / W;
+  {
+    bool f;
+    uint32_t h = h_probe(S, start_idx, f);
+    S.hstamp[h] = S.epoch; S.hkey[h] = start_idx; S.hdist[h] = 0; S.hcame[h] = -1;
+    S.nodes = 1;
+  }
+  int heap_size = 1;
+  {
+    int sx = start_idx % W, sy = start_idx / W;
+    S.hf[0] = abs(sx - gx) + abs(sy - gy);
+    S.hg[0] = 0; S.hs[0] = 0; S.hi[0] = start_idx; S.hd[0] = -1;
+  }
+  while (heap_size > 0) {
+    const int g = S.hg[0], steps = S.hs[0], cur = S.hi[0];
+    const int prev_dir = S.hd[0];
+    heap_size--;
+    if (heap_size > 0) {
+      S.hf[0] = S.hf[heap_size]; S.hg[0] = S.hg[heap_size]; S.hs[0] = S.hs[heap_size]; S.hi[0] = S.hi[heap_size];
+      S.hd[0] = S.hd[heap_size];
+      int idx = 0;  // heap_sift_down
+      for (;;) {
+        int left = 2 * idx + 1, right = left + 1, smallest = idx;
+        if (left < heap_size && S.hf[left] < S.hf[smallest]) smallest = left;
+        if (right < heap_size && S.hf[right] < S.hf[smallest]) smallest = right;
+        if (smallest == idx) break;
+        heap_swap(S, idx, smallest);
+        idx = smallest;
+      }
+    }
+    if (cur == goal_idx) {
+      int len = 0;
+      for (int idx = cur; idx != start_idx;) {
+        bool f;
+        uint32_t h = h_probe(S, idx, f);
+        idx = S.hcame[h];
+        len++;
+      }
+      if (len > out_cap) return -1;
+      int k = len;
+      for (int idx = cur; idx != start_idx;) {
+        out[--k] = idx;
+        bool f;
+        uint32_t h = h_probe(S, idx, f);
+        idx = S.hcame[h];
+      }
+      return len;
+    }
+    if (g > h_dist(S, cur)) continue;
+    S.expansions++;
+    const int cx = cur % W, cy = cur / W;
+    const uint8_t bits = d.allowed[cur];
+    for (int dd = 0; dd < 4; dd++) {
+      const int nx = cx + (dd == 1) - (dd == 3), ny = cy + (dd == 0) - (dd == 2);
+      if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
+      const int ns = steps + 1;
+      if (ns > maximum_steps) continue;
+      const int nidx = ny * W + nx;
+      double ng = g + 1;
+      if (P.turn_penalty_enabled && prev_dir != -1 && dd != prev_dir) ng += P.turn_penalty;
+      if ((bits & (1 << dd)) == 0) {
+        if (ignore_flow && d.is_road[nidx] == 1) ng += P.contraflow_penalty;
+        else continue;
+      }
+      if (d.occ[nidx] == 1) {
+        if (soft && P.dynamic_penalties_enabled) {
+          double p = P.obstacle_penalty_vehicle;
+          double local_density = (double)d.density[nidx];
+          ng += (double)(long long)(p * (1.0 + P.dynamic_penalty_scale * local_density));
+        } else if (soft) ng += P.obstacle_penalty_vehicle;
+        else continue;
+      }
+      if (d.stop[nidx] == 1) {
+        if (soft) ng += P.obstacle_penalty_stop;
+        else continue;
+      }
+      if (P.road_type_penalties_enabled && d.is_road[nidx] == 1) {
+        int rt = d.road_type[nidx];
+        if (rt == 1) ng += P.road_type_penalty_r1;
+        else if (rt == 2) ng += P.road_type_penalty_r2;
+        else if (rt == 3) ng += P.road_type_penalty_r3;
+      }
+      bool found;
+      uint32_t h = h_probe(S, nidx, found);
+      if (ng < (double)(found ? S.hdist[h] : A_INF)) {
+        S.relaxations++;
+        if (!found) {
+          if (S.nodes >= S.cap) return -1;
+          S.nodes++;
+          S.hstamp[h] = S.epoch; S.hkey[h] = nidx;
+        }
+        S.hdist[h] = (int)ng; S.hcame[h] = cur;
+        if (heap_size >= S.heap_cap) return -1;
+        int i = heap_size;
+        S.hf[i] = (int)(ng + (double)(abs(nx - gx) + abs(ny - gy)));
+        S.hg[i] = (int)ng; S.hs[i] = ns; S.hi[i] = nidx; S.hd[i] = (int8_t)dd;
+        while (i > 0) {  // heap_sift_up
+          int parent = (i - 1) / 2;
+          if (S.hf[i] < S.hf[parent]) { heap_swap(S, i, parent); i = parent; } else break;
+        }
+        heap_size++;
+      }
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vehicle working state for one step_decide
+// ---------------------------------------------------------------------------------------------
+struct VW {
+  int vid, i, pos, target;
+  uint16_t f;
+  int base, cur, cooldown, over_dur, det_dur, stuck_ticks;
+  // current path: pool-resident direction string, or cells in S.P
+  bool newpath;
+  int plen, pcur;
+  uint32_t off;
+  // aux paths k: 0 overtake_path, 1 pre_overtake_path, 2 stuck_detour_path, 3 pre_stuck_detour_path
+  bool ax_staged[4];
+  int ax_len[4];  // -1 = None
+  int d_overtaking, d_detour;
+};
+
+__device__ __forceinline__ int32_t* ax_buf(const AScratch& S, int k) { return k == 0 ? S.OV : k == 1 ? S.PO : k == 2 ? S.DV : S.PD; }
+
+// sequential reader over an aux path (staged cells or pool-resident directions)
+struct AxReader {
+  const int32_t* cells;
+  const uint32_t* pool;
+  uint32_t off;
+  int cell, idx, W;
+  __device__ void init(const Dev& d, const AScratch& S, const VW& v, int k) {
+    idx = 0; W = d.W; pool = d.pool;
+    if (v.ax_staged[k]) { cells = ax_buf(S, k); }
+    else { cells = nullptr; off = d.ax_off[k][v.vid]; cell = d.ax_start[k][v.vid]; }
+  }
+  __device__ __forceinline__ int next() {
+    if (cells) return cells[idx++];
+    cell = step_cell(cell, path_dir(pool, off, idx++), W);
+    return cell;
+  }
+};
+
+__device__ __forceinline__ int vw_path_cell(const Dev& d, const AScratch* S, const VW& v, int k, int& walk) {
+  // k-th remaining cell; `walk` carries the running cell for pool-resident paths (call with k ascending)
+  if (v.newpath) return S->P[k];
+  walk = step_cell(walk, path_dir(d.pool, v.off, v.pcur + k), d.W);
+  return walk;
+}
+
+// _scan_ahead_for_obstacles (vehicle_base.py:422-452)
+__device__ void scan_ahead_dev(const Dev& d, const TsParams& P, const AScratch* S, const VW& v, int& idx_stop,
+                               int& idx_veh, int& first_cell) {
+  idx_stop = -1; idx_veh = -1; first_cell = -1;
+  int look = min(P.vehicle_awareness_range, v.plen);
+  int walk = v.pos;
+  for (int k = 0; k < look; k++) {
+    int c = vw_path_cell(d, S, v, k, walk);
+    if (k == 0) first_cell = c;
+    if (idx_stop < 0 && d.stop[c] == 1) idx_stop = k;
+    if (idx_veh < 0 && d.occ[c] == 1) idx_veh = k;
+    if (idx_stop == 0 || idx_veh == 0) break;
+  }
+}
+
+__device__ __forceinline__ void swap_ptr(int32_t*& a, int32_t*& b) { int32_t* t = a; a = b; b = t; }
+
+// _compute_path_internal (vehicle_base.py:199-420).  On success the result is in S.P[0..*out_len) (possibly
+// empty).  Returns false on tier overflow.
+__device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScratch& S, VW& v, int& out_len) {
+  // ---- phase 0: re-merge with the saved original path (219-277) ----
+  for (int which = 0; which < 2; which++) {
+    const int kb = which == 0 ? 0 : 2, kp = kb + 1;  // bypass slot, pre-path slot
+    const bool active = which == 0 ? (v.f & VF_OVER) != 0 : (v.f & VF_DETOUR) != 0;
+    if (!active || v.ax_len[kp] <= 0) continue;
+    AxReader r;
+    r.init(d, S, v, kp);
+    int merge_idx = -1, b = -1;
+    for (int q = 0; q < v.ax_len[kp]; q++) {
+      int c = r.next();
+      if (d.occ[c] == 0) { merge_idx = q; b = c; break; }
+    }
+    if (merge_idx < 0) continue;
+    int bl = astar_dev(d, P, S, v.pos, b, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
+    if (bl < 0) return false;
+    if (bl > 0 && S.BYP[bl - 1] == b) {
+      int n = 0;
+      for (int q = 0; q < bl; q++) S.T[n++] = S.BYP[q];
+      int rest = v.ax_len[kp] - (merge_idx + 1);
+      if (n + rest > S.cap) return false;
+      for (int q = 0; q < rest; q++) S.T[n++] = r.next();
+      int32_t* dst = ax_buf(S, kb);
+      for (int q = 0; q < bl; q++) dst[q] = S.BYP[q];
+      v.ax_staged[kb] = true; v.ax_len[kb] = bl;
+      swap_ptr(S.P, S.T);
+      out_len = n;
+      return true;
+    }
+  }
+  // ---- phase 1: strict; phase 2: soft obstacles (280-306) ----
+  const int sx_goal = v.target;
+  int la = astar_dev(d, P, S, v.pos, sx_goal, false, false, 0x7FFFFFFF, S.A, S.cap);
+  if (la < 0) return false;
+  if (la == 0) {
+    la = astar_dev(d, P, S, v.pos, sx_goal, true, false, 0x7FFFFFFF, S.A, S.cap);
+    if (la < 0) return false;
+  }
+  // ---- phase 3: contraflow overtake of a stranded / parked blocker (309-366) ----
+  if (P.contraflow_overtake_active && la > 0) {
+    int idx_stop = -1, idx_veh = -1;
+    int look = min(P.vehicle_awareness_range, la);
+    for (int q = 0; q < look; q++) {
+      if (idx_stop < 0 && d.stop[S.A[q]] == 1) idx_stop = q;
+      if (idx_veh < 0 && d.occ[S.A[q]] == 1) idx_veh = q;
+      if (idx_stop >= 0 && idx_veh >= 0) break;
+    }
+    if (idx_veh == 0) {
+      int bk = d.cell_veh[S.A[0]];
+      if (bk >= 0 && (seen_stranded(d, bk, v.i) || (d.flags[bk] & VF_PARKED))) {
+        int bt = -1, idx_bp = -1;
+        for (int q = 0; q < la; q++) if (d.occ[S.A[q]] == 0) { bt = S.A[q]; idx_bp = q; break; }
+        if (bt >= 0) {
+          int bl = astar_dev(d, P, S, v.pos, bt, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
+          if (bl < 0) return false;
+          if (bl > 1 && S.BYP[bl - 1] == bt) {
+            // idx_bp = first index of bt in path = the index found above (first free cell)
+            int n = 0;
+            for (int q = 0; q < bl; q++) S.T[n++] = S.BYP[q];
+            if (n + (la - idx_bp - 1) > S.cap) return false;
+            for (int q = idx_bp + 1; q < la; q++) S.T[n++] = S.A[q];
+            for (int q = 0; q < la; q++) S.PO[q] = S.A[q];      // pre_overtake_path = path
+            v.ax_staged[1] = true; v.ax_len[1] = la;
+            for (int q = 0; q < bl; q++) S.OV[q] = S.BYP[q];    // overtake_path = bypass
+            v.ax_staged[0] = true; v.ax_len[0] = bl;
+            v.f |= VF_OVER;
+            v.d_overtaking++;
+            v.over_dur = 0;
+            swap_ptr(S.P, S.T);
+            out_len = n;
+            return true;
+          }
+        }
+      }
+    }
+  }
+  // ---- phase 4: stuck detour (369-418) ----
+  if (P.stuck_contraflow_enabled && la > 0) {
+    int threshold = d.inter[v.pos] == 1 ? P.stuck_contraflow_threshold_intersection : P.stuck_contraflow_threshold;
+    if (v.stuck_ticks >= threshold) {
+      int bt = -1, merge_idx = -1;
+      for (int q = 0; q < la; q++) if (d.occ[S.A[q]] == 0) { bt = S.A[q]; merge_idx = q; break; }
+      if (bt >= 0) {
+        int bl = astar_dev(d, P, S, v.pos, bt, true, true, P.max_contraflow_stuck_detour_steps, S.BYP, MAXB);
+        if (bl < 0) return false;
+        if (bl > 1 && S.BYP[bl - 1] == bt) {
+          int n = 0;
+          for (int q = 0; q < bl; q++) S.T[n++] = S.BYP[q];
+          if (n + (la - merge_idx - 1) > S.cap) return false;
+          for (int q = merge_idx + 1; q < la; q++) S.T[n++] = S.A[q];
+          for (int q = 0; q < la; q++) S.PD[q] = S.A[q];        // pre_stuck_detour_path = path.copy()
+          v.ax_staged[3] = true; v.ax_len[3] = la;
+          for (int q = 0; q < bl; q++) S.DV[q] = S.BYP[q];      // stuck_detour_path = bypass
+          v.ax_staged[2] = true; v.ax_len[2] = bl;
+          v.d_detour++;
+          v.f |= VF_DETOUR;
+          v.det_dur = 0;
+          swap_ptr(S.P, S.T);
+          out_len = n;
+          return true;
+        }
+      }
+    }
+  }
+  swap_ptr(S.P, S.A);
+  out_len = la;
+  return true;
+}
+
+// `pos not in aux path k`
+__device__ bool ax_contains(const Dev& d, const AScratch* S, const VW& v, int k, int cell) {
+  if (v.ax_len[k] <= 0) return false;
+  if (!S) {  // no scratch: only pool-resident paths can exist
+    int c = d.ax_start[k][v.vid];
+    uint32_t off = d.ax_off[k][v.vid];
+    for (int q = 0; q < v.ax_len[k]; q++) { c = step_cell(c, path_dir(d.pool, off, q), d.W); if (c == cell) return true; }
+    return false;
+  }
+  AxReader r;
+  r.init(d, *S, v, k);
+  for (int q = 0; q < v.ax_len[k]; q++) if (r.next() == cell) return true;
+  return false;
+}
+
+// device-side bump allocation in the path pool; returns false when the pool is exhausted
+__device__ __forceinline__ bool pool_alloc(const Dev& d, int words, uint32_t& off) {
+  unsigned long long o = atomicAdd((unsigned long long*)&d.cnt->pool_used, (unsigned long long)words);
+  if (o + (unsigned long long)words > (unsigned long long)d.pool_cap_words) return false;
+  off = (uint32_t)o;
+  return true;
+}
+__device__ void encode_cells(const Dev& d, uint32_t off, int start_cell, const int32_t* cells, int len) {
+  int prev = start_cell;
+  uint32_t word = 0;
+  for (int k = 0; k < len; k++) {
+    int c = cells[k];
+    int delta = c - prev;
+    int dir = delta == d.W ? 0 : delta == 1 ? 1 : delta == -d.W ? 2 : 3;
+    word |= (uint32_t)dir << ((k & 15) * 2);
+    if ((k & 15) == 15) { d.pool[off + (k >> 4)] = word; word = 0; }
+    prev = c;
+  }
+  if (len & 15) d.pool[off + (len >> 4)] = word;
+}
+
+// step_decide for vehicle number i of active_vehicle_agents.  S == nullptr: run until a search is needed
+// (returns DV_DEFER without side effects).  Otherwise completes, unless the tier overflows or the pool is full.
+__device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* S) {
+  const int vid = d.active[i];
+  if (vid < 0) return DV_DONE;
+  VW v;
+  v.vid = vid; v.i = i; v.pos = d.pos[vid]; v.target = d.target[vid];
+  v.f = d.flags[vid] & ~VF_EARLY;
+  const uint8_t ev = d.ev[vid];
+  v.base = d.base_speed[vid]; v.cur = d.cur_speed[vid];
+  bool early = false;
+  int stranded_left = d.stranded_left[vid];
+  bool write_stranded = false;
+  int dc_coll = 0, dc_malf = 0;
+  if (ev == 1) {  // became stranded at its own decide point: state already written by k_apply_event
+    v.base = 0; v.cur = 0; early = true;
+  } else {
+    if (ev != 2 && (v.f & (VF_COLL | VF_MALF))) {  // _tick_stranded (552-565)
+      stranded_left -= 1;
+      if (stranded_left <= 0) {
+        if (v.f & VF_COLL) dc_coll--;
+        if (v.f & VF_MALF) dc_malf--;
+        v.f &= ~(VF_COLL | VF_MALF);
+        stranded_left = 0;
+      }
+      write_stranded = true;
+      if (v.f & (VF_COLL | VF_MALF)) { v.base = 0; v.cur = 0; early = true; }
+    }
+    if (!early && !P.malfunction_active) {  // `not ACTIVE or ...` (609): malfunction without a draw
+      v.f = (v.f | VF_MALF) & ~VF_COLL;
+      stranded_left = P.malfunction_duration; write_stranded = true;
+      dc_malf++;
+      v.base = 0; v.cur = 0; early = true;
+    }
+    if (!early && d.stop[v.pos] == 1) { v.base = 0; v.cur = 0; early = true; }
+  }
+  int max_steps = d.max_steps[vid];
+  bool path_changed = false, reached_body = false;
+  v.newpath = false;
+  v.d_overtaking = 0; v.d_detour = 0;
+  for (int k = 0; k < 4; k++) { v.ax_staged[k] = false; v.ax_len[k] = 0; }
+  bool ax_none_set[2] = {false, false};
+  if (!early) {
+    if (v.base == 0) v.base = d.R[i];  // _choose_new_speed: rolled by the host scan
+    int speed = v.base;
+    if (P.rain_enabled && d.rain[v.pos] == 1) speed = max(1, speed - P.rain_speed_reduction);
+    v.cur = speed;
+    v.off = d.path_off[vid]; v.pcur = d.path_cur[vid]; v.plen = d.path_len[vid] - v.pcur;
+    v.cooldown = d.cooldown[vid]; v.over_dur = d.over_dur[vid]; v.det_dur = d.det_dur[vid];
+    v.stuck_ticks = d.stuck_ticks[vid];
+    for (int k = 0; k < 4; k++) { v.ax_staged[k] = false; v.ax_len[k] = d.ax_len[k][vid]; }
+    // _recompute_path_on_stuck (506-517): self.path = self._compute_path(use_cache=False)
+    const int thresh = d.inter[v.pos] == 1 ? P.stuck_recompute_threshold_intersection : P.stuck_recompute_threshold;
+    if (v.stuck_ticks >= thresh) {
+      if (!S) return DV_DEFER;
+      v.cooldown = P.pathfinding_cooldown;
+      int len;
+      if (!compute_path_internal_dev(d, P, *S, v, len)) return DV_OVERFLOW;
+      v.newpath = true; v.plen = len; path_changed = true;
+    }
+    // _recompute_path_on_obstacle (454-504)
+    if ((v.f & VF_OVER) && (v.ax_len[0] <= 0 || !ax_contains(d, S, v, 0, v.pos))) {
+      v.ax_len[0] = -1; v.ax_staged[0] = false; ax_none_set[0] = true; v.f &= ~VF_OVER;
+    }
+    if ((v.f & VF_DETOUR) && (v.ax_len[2] <= 0 || !ax_contains(d, S, v, 2, v.pos))) {
+      v.ax_len[2] = -1; v.ax_staged[2] = false; ax_none_set[1] = true; v.f &= ~VF_DETOUR;
+    }
+    int idx_stop, idx_veh, first_cell;
+    scan_ahead_dev(d, P, S, v, idx_stop, idx_veh, first_cell);
+    bool done_obst = false;
+    if (v.f & VF_OVER) {
+      v.over_dur += 1;
+      if (v.over_dur <= P.contraflow_overtake_duration) done_obst = true;
+    }
+    if (!done_obst && (v.f & VF_DETOUR)) {
+      v.det_dur += 1;
+      if (v.det_dur <= P.contraflow_stuck_detour_duration) done_obst = true;
+    }
+    if (!done_obst && v.cooldown > 0) {
+      if (idx_veh == 0) {
+        int b = d.cell_veh[first_cell];
+        if (b >= 0 && (seen_stranded(d, b, i) || (d.flags[b] & VF_PARKED))) {
+          // immediate pathfinding
+        } else { v.cooldown -= 1; done_obst = true; }
+      } else { v.cooldown -= 1; done_obst = true; }
+    }
+    if (!done_obst && (idx_stop >= 0 || idx_veh >= 0)) {
+      if (!S) return DV_DEFER;
+      // path = self._compute_path(use_cache=False); adopted only when non-empty (498-502).  The planner
+      // never writes through S->P, it only swaps buffer pointers at the end, so a previous result of this
+      // tick (stuck replan) survives an empty answer and is swapped back.
+      v.cooldown = P.pathfinding_cooldown;
+      const bool keep_new = v.newpath;
+      int len;
+      if (!compute_path_internal_dev(d, P, *S, v, len)) return DV_OVERFLOW;
+      if (len > 0) {
+        v.newpath = true; v.plen = len; path_changed = true;
+        scan_ahead_dev(d, P, S, v, idx_stop, idx_veh, first_cell);
+      } else if (keep_new) {
+        swap_ptr(S->P, S->A);  // undo the final swap of the empty result
+      }
+    }
+    // _determine_max_steps (719-731)
+    int ms = min(v.cur, v.plen);
+    bool blocked = false;
+    if (idx_stop >= 0) ms = min(ms, idx_stop);
+    if (idx_veh >= 0) { if (idx_veh == 0) blocked = true; ms = min(ms, idx_veh); }
+    max_steps = ms;
+    v.f = blocked ? (v.f | VF_BLOCKED) : (v.f & ~VF_BLOCKED);
+    if (ms <= 0) {
+      v.base = 0;
+      if (v.pos == v.target) atomicExch(&d.cnt->error, TS_E_UNSUPPORTED);  // despawn inside decide (start == goal)
+      early = true;
+    }
+    reached_body = true;
+  }
+  if (ev == 2) { v.base = 0; v.cur = 0; }  // collision inflicted after this vehicle had decided
+  // ---------------- commit (first the allocation that can fail, then everything else) ----------------
+  if (reached_body && S) {
+    int words = path_changed ? (v.plen + 15) / 16 : 0;
+    for (int k = 0; k < 4; k++) if (v.ax_staged[k]) words += (v.ax_len[k] + 15) / 16;
+    uint32_t off = 0;
+    if (words > 0 && !pool_alloc(d, words, off)) return DV_POOL_FULL;
+    if (path_changed) {
+      encode_cells(d, off, v.pos, S->P, v.plen);
+      d.path_off[vid] = off; d.path_len[vid] = v.plen; d.path_cur[vid] = 0;
+      off += (v.plen + 15) / 16;
+    }
+    for (int k = 0; k < 4; k++) {
+      if (!v.ax_staged[k]) continue;
+      encode_cells(d, off, v.pos, ax_buf(*S, k), v.ax_len[k]);
+      d.ax_start[k][vid] = v.pos; d.ax_off[k][vid] = off; d.ax_len[k][vid] = v.ax_len[k];
+      off += (v.ax_len[k] + 15) / 16;
+    }
+  }
+  if (reached_body) {
+    if (ax_none_set[0] && !v.ax_staged[0]) d.ax_len[0][vid] = -1;
+    if (ax_none_set[1] && !v.ax_staged[2]) d.ax_len[2][vid] = -1;
+    d.cooldown[vid] = v.cooldown; d.over_dur[vid] = v.over_dur; d.det_dur[vid] = v.det_dur;
+    if (v.d_overtaking) atomicAdd((unsigned long long*)&d.cnt->overtaking, (unsigned long long)v.d_overtaking);
+    if (v.d_detour) atomicAdd((unsigned long long*)&d.cnt->in_stuck_detour, (unsigned long long)v.d_detour);
+  }
+  if (write_stranded) d.stranded_left[vid] = stranded_left;
+  if (dc_coll) atomicAdd((unsigned long long*)&d.cnt->collisions, (unsigned long long)(long long)dc_coll);
+  if (dc_malf) atomicAdd((unsigned long long*)&d.cnt->malfunctions, (unsigned long long)(long long)dc_malf);
+  d.max_steps[vid] = (int8_t)max_steps;
+  d.base_speed[vid] = (int8_t)v.base;
+  d.cur_speed[vid] = (int8_t)v.cur;
+  d.flags[vid] = early ? (v.f | VF_EARLY) : v.f;
+  return DV_DONE;
+}
+
+// every live vehicle: the part of step_decide that needs no search; the others go to the replan list
+__global__ void k_decide_main(Dev d, TsParams P, int n_active, int32_t* replan_list) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_active) return;
+  if (decide_vehicle(d, P, i, nullptr) == DV_DEFER) replan_list[atomicAdd(&d.cnt->replan_n[0], 1)] = i;
+}
+
+// replanning vehicles: one lane per vehicle, private scratch from tier `t`.  Entries that outgrow the tier go
+// to `next_list` (counter replan_n[next_counter]); entries that find the pool full go to `retry_list`.
+__global__ void k_decide_replan(Dev d, TsParams P, ATier t, const int32_t* list, int begin, int n, int32_t* next_list,
+                                int next_counter, int32_t* retry_list) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  AScratch S;
+  scratch_bind(t, j, S);
+  const int i = list[begin + j];
+  int r = decide_vehicle(d, P, i, &S);
+  t.slot_epoch[j] = S.epoch;
+  if (r == DV_DONE) {  // work of attempts that are re-run on a larger tier / after pool growth is not counted twice
+    atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
+    atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
+    atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
+  }
+  if (r == DV_OVERFLOW) next_list[atomicAdd(&d.cnt->replan_n[next_counter], 1)] = i;
+  else if (r == DV_POOL_FULL) retry_list[atomicAdd(&d.cnt->replan_n[3], 1)] = i;
+}
+
+// one search on the current maps (the `astar(...)` operator seam, ts_astar) - slot 0 of tier `t`
+__global__ void k_astar_single(Dev d, TsParams P, ATier t, int start_idx, int goal_idx, int soft, int ignore_flow,
+                               int maximum_steps, int32_t* out_len) {
+  if (threadIdx.x || blockIdx.x) return;
+  AScratch S;
+  scratch_bind(t, 0, S);
+  int len = astar_dev(d, P, S, start_idx, goal_idx, soft != 0, ignore_flow != 0, maximum_steps, S.A, S.cap);
+  t.slot_epoch[0] = S.epoch;
+  if (len >= 0) {
+    atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
+    atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
+    atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
+  }
+  *out_len = len;  // -1 = tier overflow; the path cells are in the slot's A buffer
+}
+
+// VehicleAgent.__init__ -> self.path = self._compute_path() on a cache miss (vehicle_base.py:80-81, 143-167):
+// the phase 0-4 planner for a freshly placed vehicle.  status: path length, or -1 overflow / -2 pool full.
+__global__ void k_spawn_plan(Dev d, TsParams P, ATier t, int vid, int32_t* status) {
+  if (threadIdx.x || blockIdx.x) return;
+  AScratch S;
+  scratch_bind(t, 0, S);
+  VW v;
+  v.vid = vid; v.i = d.active_idx[vid]; v.pos = d.pos[vid]; v.target = d.target[vid];
+  v.f = d.flags[vid]; v.base = 0; v.cur = 0; v.cooldown = P.pathfinding_cooldown;
+  v.over_dur = d.over_dur[vid]; v.det_dur = d.det_dur[vid]; v.stuck_ticks = d.stuck_ticks[vid];
+  v.newpath = false; v.plen = 0; v.pcur = 0; v.off = 0; v.d_overtaking = 0; v.d_detour = 0;
+  for (int k = 0; k < 4; k++) { v.ax_staged[k] = false; v.ax_len[k] = d.ax_len[k][vid]; }
+  int len;
+  bool ok = compute_path_internal_dev(d, P, S, v, len);
+  t.slot_epoch[0] = S.epoch;
+  if (!ok) { *status = -1; return; }
+  int words = (len + 15) / 16;
+  for (int k = 0; k < 4; k++) if (v.ax_staged[k]) words += (v.ax_len[k] + 15) / 16;
+  uint32_t off = 0;
+  if (words > 0 && !pool_alloc(d, words, off)) { *status = -2; return; }
+  atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
+  atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
+  atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
+  encode_cells(d, off, v.pos, S.P, len);
+  d.path_off[vid] = off; d.path_len[vid] = len; d.path_cur[vid] = 0;
+  off += (len + 15) / 16;
+  for (int k = 0; k < 4; k++) {
+    if (!v.ax_staged[k]) continue;
+    encode_cells(d, off, v.pos, ax_buf(S, k), v.ax_len[k]);
+    d.ax_start[k][vid] = v.pos; d.ax_off[k][vid] = off; d.ax_len[k][vid] = v.ax_len[k];
+    off += (v.ax_len[k] + 15) / 16;
+  }
+  d.flags[vid] = v.f; d.over_dur[vid] = v.over_dur; d.det_dur[vid] = v.det_dur;
+  if (v.d_overtaking) atomicAdd((unsigned long long*)&d.cnt->overtaking, (unsigned long long)v.d_overtaking);
+  if (v.d_detour) atomicAdd((unsigned long long*)&d.cnt->in_stuck_detour, (unsigned long long)v.d_detour);
+  *status = len;
+}
+
+// path-pool garbage collection: every live vehicle copies the words it still needs into a fresh pool
+__global__ void k_pool_gc(Dev d, int n_active, uint32_t* new_pool, unsigned long long* new_used) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_active) return;
+  int vid = d.active[i];
+  if (vid < 0) return;
+  {
+    int cur = d.path_cur[vid], len = d.path_len[vid];
+    int w0 = cur >> 4, w1 = (len + 15) >> 4;
+    int words = w1 - w0;
+    uint32_t src = d.path_off[vid] + w0;
+    uint32_t dst = words > 0 ? (uint32_t)atomicAdd(new_used, (unsigned long long)words) : 0u;
+    for (int q = 0; q < words; q++) new_pool[dst + q] = d.pool[src + q];
+    d.path_off[vid] = dst; d.path_cur[vid] = cur & 15; d.path_len[vid] = len - (w0 << 4);
+  }
+  for (int k = 0; k < 4; k++) {
+    int len = d.ax_len[k][vid];
+    if (len <= 0) continue;
+    int words = (len + 15) >> 4;
+    uint32_t src = d.ax_off[k][vid];
+    uint32_t dst = (uint32_t)atomicAdd(new_used, (unsigned long long)words);
+    for (int q = 0; q < words; q++) new_pool[dst + q] = d.pool[src + q];
+    d.ax_off[k][vid] = dst;
+  }
+}
+
+}  // namespace

@@ -1,0 +1,105 @@
+// dev.h - device-side state (structure-of-arrays in HBM) and small helpers shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "../../include/trafficsim.h"
+
+#define BLK 256
+
+namespace {
+
+// vehicle flag bits: TS_F_* (1..256) plus engine-private ones
+constexpr uint16_t VF_EARLY = TS_F_EARLY_EXIT, VF_STUCK = TS_F_STUCK, VF_PARKED = TS_F_PARKED,
+                   VF_COLL = TS_F_COLLISION, VF_MALF = TS_F_MALFUNCTION, VF_OVER = TS_F_OVERTAKING,
+                   VF_DETOUR = TS_F_DETOUR, VF_BLOCKED = TS_F_BLOCKED, VF_HASPREV = TS_F_HAS_PREV,
+                   VF_KEEP = 512 /* remove_on_arrival == False */, VF_ALIVE = 1024;
+constexpr int8_t K_VEHICLE = 100, K_DEAD = -1;
+constexpr uint32_t RANK_BITS = 22, RANK_MASK = (1u << RANK_BITS) - 1, EPOCHS = 1u << (32 - RANK_BITS);
+constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
+
+// decide-phase flag byte F (k_decide_pre -> host scan)
+constexpr uint8_t F_DRAW_MALF = 1, F_DRAW_SWIPE = 2, F_DRAW_SPEED = 4;
+
+struct DevCnt {
+  long long stuck, collisions, malfunctions, overtaking, in_stuck_detour, parked, live_internal, live_through,
+      completed_internal, completed_through, dist_internal, dist_through;
+  double dur_internal, dur_through;
+  int resolved;    // agents stepped so far in this move phase
+  int deaths;      // vehicles removed this tick
+  int need_astar;  // unused (kept for layout)
+  int error;       // sticky device-side error
+  int replan_n[6]; // work-list lengths: tier 0, tier 1, tier 2, pool-full retries, beyond the last tier, pad
+  unsigned long long pool_used;  // words handed out from the path pool (device-side bump allocator)
+  long long astar_calls, astar_exp, astar_relax;
+};
+
+struct Dev {
+  int W, H, N;
+  int8_t *occ, *stop, *stuck, *rain;
+  uint8_t* allowed;
+  int8_t *is_road, *road_type, *inter;
+  // vehicles (indexed by vehicle id = spawn index)
+  int32_t *pos, *target, *path_len, *path_cur, *stuck_ticks, *cooldown, *stranded_left, *steps, *over_dur, *det_dur,
+      *next_in_cell, *active_idx, *sched_slot;
+  uint32_t* path_off;
+  int8_t *base_speed, *cur_speed, *max_steps, *dir, *pop;
+  uint16_t* flags;
+  double* depart;
+  uint8_t *ev, *st_before, *st_after;
+  int32_t* ev_idx;  // decide-order index of the event that stranded this vehicle this tick (valid when ev != 0)
+  uint32_t* pool;
+  unsigned long long pool_cap_words;
+  // contraflow aux paths, k: 0 overtake_path, 1 pre_overtake_path, 2 stuck_detour_path, 3 pre_stuck_detour_path
+  // (vehicle_base.py:45-54) as (cell before the first element, pool offset, length; -1 = None)
+  int32_t* ax_start[4];
+  uint32_t* ax_off[4];
+  int32_t* ax_len[4];
+  float* density;    // _update_density_map (city_model.py:1764-1778), materialised on demand
+  int8_t* occ_snap;  // occupancy at the last tick start (what density_map is a function of)
+  int32_t* cell_veh;  // first vehicle in the cell's MultiGrid list, -1 = none
+  // ordered lists
+  int32_t* active;    // active_vehicle_agents (vehicle ids, -1 = removed this tick)
+  int8_t* sched_kind;
+  int32_t* sched_ref;
+  uint32_t* rank;     // per schedule slot
+  uint8_t* resolved;  // per schedule slot, this move phase
+  // light groups (CSR tables + state)
+  int G;
+  int32_t *g_light_off, *light_cell, *light_ctrl_off, *light_ctrl, *g_ns_off, *g_ns, *g_ew_off, *g_ew, *g_icell_off,
+      *g_icell, *g_nsin_off, *g_nsin, *g_nsout_off, *g_nsout, *g_ewin_off, *g_ewin, *g_ewout_off, *g_ewout, *g_nb,
+      *g_nb_ctor, *g_slot;
+  int32_t *gs_cur, *gs_pend, *gs_trans, *gs_clear, *gs_ftphase, *gs_fttimer, *gs_qtimer, *gs_gap, *gs_last, *gs_nsp,
+      *gs_ewp, *gs_repop;
+  // per-cell min-rank claims for the move phase (epoch-tagged so they never need clearing)
+  uint32_t *cw_occ, *cr_occ, *cw_stop, *cr_stop, *gclaim_r;
+  // decide-phase exchange buffers
+  uint8_t *F, *R;
+  int32_t* cand;
+  DevCnt* cnt;
+};
+
+__device__ __forceinline__ int path_dir(const uint32_t* pool, uint32_t off, int k) {
+  return (pool[off + ((uint32_t)k >> 4)] >> ((k & 15) * 2)) & 3;
+}
+__device__ __forceinline__ int step_cell(int cell, int dir, int W) {
+  return dir == 0 ? cell + W : dir == 1 ? cell + 1 : dir == 2 ? cell - W : cell - 1;
+}
+__device__ __forceinline__ uint32_t claim_rank(uint32_t v, uint32_t prefix) {
+  return (v >> RANK_BITS) == prefix ? (v & RANK_MASK) : NO_RANK;
+}
+
+// "is ag stranded, as vehicle number my_idx of the decide order sees it" - earlier vehicles have already
+// run their step_decide this tick (countdown applied, events visible), later ones have not.
+__device__ __forceinline__ bool seen_stranded(const Dev& d, int ag, int my_idx) {
+  const uint8_t e = d.ev[ag];
+  if (e) {  // stranded by a malfunction / sideswipe found during this tick's decide phase, at order index j
+    const int j = d.ev_idx[ag];
+    if (e == 1) return j < my_idx ? true : (d.st_before[ag] != 0);  // the vehicle that drew the event (j = its own index)
+    return j < my_idx;                                                // its partner: a valid candidate, so fine until then
+  }
+  if (d.active_idx[ag] < my_idx) return d.st_after[ag] != 0;
+  return d.st_before[ag] != 0;
+}
+
+
+}  // namespace

@@ -20,89 +20,16 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/trafficsim.h"
 #include "mt19937.h"
 
-#define BLK 256
+#include "dev.h"
+#include "astar.h"
 
 namespace {
-
-// vehicle flag bits: TS_F_* (1..256) plus engine-private ones
-constexpr uint16_t VF_EARLY = TS_F_EARLY_EXIT, VF_STUCK = TS_F_STUCK, VF_PARKED = TS_F_PARKED,
-                   VF_COLL = TS_F_COLLISION, VF_MALF = TS_F_MALFUNCTION, VF_OVER = TS_F_OVERTAKING,
-                   VF_DETOUR = TS_F_DETOUR, VF_BLOCKED = TS_F_BLOCKED, VF_HASPREV = TS_F_HAS_PREV,
-                   VF_KEEP = 512 /* remove_on_arrival == False */, VF_ALIVE = 1024;
-constexpr int8_t K_VEHICLE = 100, K_DEAD = -1;
-constexpr uint32_t RANK_BITS = 22, RANK_MASK = (1u << RANK_BITS) - 1, EPOCHS = 1u << (32 - RANK_BITS);
-constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
-
-// decide-phase flag byte F (k_decide_pre -> host scan)
-constexpr uint8_t F_DRAW_MALF = 1, F_DRAW_SWIPE = 2, F_DRAW_SPEED = 4;
-
-struct DevCnt {
-  long long stuck, collisions, malfunctions, overtaking, in_stuck_detour, parked, live_internal, live_through,
-      completed_internal, completed_through, dist_internal, dist_through;
-  double dur_internal, dur_through;
-  int resolved;    // agents stepped so far in this move phase
-  int deaths;      // vehicles removed this tick
-  int need_astar;  // replans requested by k_decide_main (GPU A* not built yet -> TS_E_UNSUPPORTED)
-  int error;       // sticky device-side error
-};
-
-struct Dev {
-  int W, H, N;
-  int8_t *occ, *stop, *stuck, *rain;
-  uint8_t* allowed;
-  int8_t *is_road, *road_type, *inter;
-  // vehicles (indexed by vehicle id = spawn index)
-  int32_t *pos, *target, *path_len, *path_cur, *stuck_ticks, *cooldown, *stranded_left, *steps, *over_dur, *det_dur,
-      *next_in_cell, *active_idx, *sched_slot;
-  uint32_t* path_off;
-  int8_t *base_speed, *cur_speed, *max_steps, *dir, *pop;
-  uint16_t* flags;
-  double* depart;
-  uint8_t *ev, *st_before, *st_after;
-  uint32_t* pool;
-  int32_t* cell_veh;  // first vehicle in the cell's MultiGrid list, -1 = none
-  // ordered lists
-  int32_t* active;    // active_vehicle_agents (vehicle ids, -1 = removed this tick)
-  int8_t* sched_kind;
-  int32_t* sched_ref;
-  uint32_t* rank;     // per schedule slot
-  uint8_t* resolved;  // per schedule slot, this move phase
-  // light groups (CSR tables + state)
-  int G;
-  int32_t *g_light_off, *light_cell, *light_ctrl_off, *light_ctrl, *g_ns_off, *g_ns, *g_ew_off, *g_ew, *g_icell_off,
-      *g_icell, *g_nsin_off, *g_nsin, *g_nsout_off, *g_nsout, *g_ewin_off, *g_ewin, *g_ewout_off, *g_ewout, *g_nb,
-      *g_nb_ctor, *g_slot;
-  int32_t *gs_cur, *gs_pend, *gs_trans, *gs_clear, *gs_ftphase, *gs_fttimer, *gs_qtimer, *gs_gap, *gs_last, *gs_nsp,
-      *gs_ewp, *gs_repop;
-  // per-cell min-rank claims for the move phase (epoch-tagged so they never need clearing)
-  uint32_t *cw_occ, *cr_occ, *cw_stop, *cr_stop, *gclaim_r;
-  // decide-phase exchange buffers
-  uint8_t *F, *R;
-  int32_t* cand;
-  DevCnt* cnt;
-};
-
-__device__ __forceinline__ int path_dir(const uint32_t* pool, uint32_t off, int k) {
-  return (pool[off + ((uint32_t)k >> 4)] >> ((k & 15) * 2)) & 3;
-}
-__device__ __forceinline__ int step_cell(int cell, int dir, int W) {
-  return dir == 0 ? cell + W : dir == 1 ? cell + 1 : dir == 2 ? cell - W : cell - 1;
-}
-__device__ __forceinline__ uint32_t claim_rank(uint32_t v, uint32_t prefix) {
-  return (v >> RANK_BITS) == prefix ? (v & RANK_MASK) : NO_RANK;
-}
-
-// "is ag stranded, as vehicle number my_idx of the decide order sees it" - earlier vehicles have already
-// run their step_decide this tick (countdown applied, events visible), later ones have not.
-__device__ __forceinline__ bool seen_stranded(const Dev& d, int ag, int my_idx) {
-  if (d.active_idx[ag] < my_idx) return d.ev[ag] ? true : (d.st_after[ag] != 0);
-  return d.st_before[ag] != 0;
-}
 
 // ---------------------------------------------------------------------------------------------
 // decide, part 1 (pure): which draws of the global MT19937 stream does each vehicle consume?
@@ -156,123 +83,49 @@ __global__ void k_decide_pre(Dev d, TsParams P, int start, int n_active) {
 }
 
 // _set_malfunction / _set_collision (vehicle_base.py:534-550) for the (rare) events the host scan finds.
-// ev: 1 = stranded at its own decide point (early exit there); 2 = hit by a later vehicle after deciding.
+// ev: 1 = stranded at its own decide point (early exit there); 2 = hit by a later vehicle after deciding;
+// 3 = hit before its own turn (it will find itself stranded).  ev_idx = decide-order index of the event.
 __global__ void k_apply_event(Dev d, TsParams P, int vid, int is_collision, int partner, int my_idx) {
   if (threadIdx.x || blockIdx.x) return;
+  {
+    // the vehicle reached its draws, so a stranding it still carried from earlier ticks expired in this very
+    // step_decide (_tick_stranded, vehicle_base.py:556-564): do that bookkeeping before the new stranding
+    uint16_t f0 = d.flags[vid];
+    if (f0 & VF_COLL) atomicAdd((unsigned long long*)&d.cnt->collisions, (unsigned long long)-1LL);
+    if (f0 & VF_MALF) atomicAdd((unsigned long long*)&d.cnt->malfunctions, (unsigned long long)-1LL);
+    d.flags[vid] = f0 & ~(VF_COLL | VF_MALF);
+  }
   if (!is_collision) {
     d.flags[vid] = (d.flags[vid] | VF_MALF) & ~VF_COLL;
     d.stranded_left[vid] = P.malfunction_duration;
     d.base_speed[vid] = 0; d.cur_speed[vid] = 0;
-    d.ev[vid] = 1;
+    d.ev[vid] = 1; d.ev_idx[vid] = my_idx;
     atomicAdd((unsigned long long*)&d.cnt->malfunctions, 1ULL);
   } else {
     d.flags[vid] = (d.flags[vid] | VF_COLL) & ~VF_MALF;
     d.stranded_left[vid] = P.sideswipe_duration;
     d.base_speed[vid] = 0; d.cur_speed[vid] = 0;
-    d.ev[vid] = 1;
+    d.ev[vid] = 1; d.ev_idx[vid] = my_idx;
+    {
+      // an earlier partner that was a valid candidate had any old stranding expire in its own step_decide of
+      // this tick; its stored flags still show it because k_decide_main has not run yet
+      uint16_t pf = d.flags[partner];
+      if (pf & VF_COLL) atomicAdd((unsigned long long*)&d.cnt->collisions, (unsigned long long)-1LL);
+      if (pf & VF_MALF) atomicAdd((unsigned long long*)&d.cnt->malfunctions, (unsigned long long)-1LL);
+    }
     d.flags[partner] = (d.flags[partner] | VF_COLL) & ~VF_MALF;
     d.stranded_left[partner] = P.sideswipe_duration;
-    d.base_speed[partner] = 0; d.cur_speed[partner] = 0;
-    if (d.active_idx[partner] < my_idx) d.ev[partner] = 2;
+    if (d.active_idx[partner] < my_idx) {
+      // already decided this tick: k_decide_main still needs its pre-collision base_speed to reproduce that
+      // decision, and zeroes base/current speed itself afterwards (ev == 2)
+      d.ev[partner] = 2;
+    } else {
+      d.ev[partner] = 3;
+      d.base_speed[partner] = 0; d.cur_speed[partner] = 0;
+    }
+    d.ev_idx[partner] = my_idx;
     atomicAdd((unsigned long long*)&d.cnt->collisions, 2ULL);
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// decide, part 2: step_decide body (vehicle_base.py:616-663) with _scan_ahead_for_obstacles 422-452,
-// _recompute_path_on_stuck 506-517, _recompute_path_on_obstacle 454-504 (replans are requested, not run,
-// until the GPU A* lands), _determine_max_steps 719-731.
-// ---------------------------------------------------------------------------------------------
-__global__ void k_decide_main(Dev d, TsParams P, int n_active) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_active) return;
-  int vid = d.active[i];
-  if (vid < 0) return;
-  uint16_t f = d.flags[vid] & ~(VF_EARLY);
-  const uint8_t ev = d.ev[vid];
-  int base = d.base_speed[vid], cur = d.cur_speed[vid];
-  const int pos = d.pos[vid];
-  bool early = false;
-  if (ev == 1) {  // became stranded at its own decide point: state already written by k_apply_event
-    base = 0; cur = 0; early = true;
-  } else {
-    if (ev != 2 && (f & (VF_COLL | VF_MALF))) {  // _tick_stranded
-      int left = d.stranded_left[vid] - 1;
-      if (left <= 0) {
-        if (f & VF_COLL) atomicAdd((unsigned long long*)&d.cnt->collisions, (unsigned long long)-1LL);
-        if (f & VF_MALF) atomicAdd((unsigned long long*)&d.cnt->malfunctions, (unsigned long long)-1LL);
-        f &= ~(VF_COLL | VF_MALF);
-        left = 0;
-      }
-      d.stranded_left[vid] = left;
-      if (f & (VF_COLL | VF_MALF)) { base = 0; cur = 0; early = true; }
-    }
-    if (!early && !P.malfunction_active) {  // malfunction without a draw
-      f = (f | VF_MALF) & ~VF_COLL;
-      d.stranded_left[vid] = P.malfunction_duration;
-      atomicAdd((unsigned long long*)&d.cnt->malfunctions, 1ULL);
-      base = 0; cur = 0; early = true;
-    }
-    if (!early && d.stop[pos] == 1) { base = 0; cur = 0; early = true; }
-  }
-  if (!early) {
-    if (base == 0) base = d.R[i];  // _choose_new_speed: rolled by the host scan
-    int speed = base;
-    if (P.rain_enabled && d.rain[pos] == 1) speed = max(1, speed - P.rain_speed_reduction);
-    cur = speed;
-    bool need_astar = false;
-    // _recompute_path_on_stuck
-    int thresh = d.inter[pos] == 1 ? P.stuck_recompute_threshold_intersection : P.stuck_recompute_threshold;
-    if (d.stuck_ticks[vid] >= thresh) need_astar = true;
-    if (f & (VF_OVER | VF_DETOUR)) need_astar = true;  // contraflow state only arises from replans
-    // _scan_ahead_for_obstacles
-    const uint32_t off = d.path_off[vid];
-    const int pcur = d.path_cur[vid];
-    const int plen = d.path_len[vid] - pcur;
-    int idx_stop = -1, idx_veh = -1, first_cell = -1;
-    {
-      int look = min(P.vehicle_awareness_range, plen);
-      int c = pos;
-      for (int k = 0; k < look; k++) {
-        c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
-        if (k == 0) first_cell = c;
-        if (idx_stop < 0 && d.stop[c] == 1) idx_stop = k;
-        if (idx_veh < 0 && d.occ[c] == 1) idx_veh = k;
-        if (idx_stop == 0 || idx_veh == 0) break;
-      }
-    }
-    // _recompute_path_on_obstacle (cooldown gate; the replan itself needs A*)
-    if (!need_astar) {
-      int cd = d.cooldown[vid];
-      bool gate_open = true;
-      if (cd > 0) {
-        if (idx_veh == 0) {
-          int b = d.cell_veh[first_cell];
-          if (b >= 0 && (seen_stranded(d, b, i) || (d.flags[b] & VF_PARKED))) {
-            // immediate pathfinding
-          } else { d.cooldown[vid] = cd - 1; gate_open = false; }
-        } else { d.cooldown[vid] = cd - 1; gate_open = false; }
-      }
-      if (gate_open && (idx_stop >= 0 || idx_veh >= 0)) need_astar = true;
-    }
-    if (need_astar) atomicAdd(&d.cnt->need_astar, 1);
-    // _determine_max_steps
-    int ms = min(cur, plen);
-    bool blocked = false;
-    if (idx_stop >= 0) ms = min(ms, idx_stop);
-    if (idx_veh >= 0) { if (idx_veh == 0) blocked = true; ms = min(ms, idx_veh); }
-    d.max_steps[vid] = (int8_t)ms;
-    f = blocked ? (f | VF_BLOCKED) : (f & ~VF_BLOCKED);
-    if (ms <= 0) {
-      base = 0;
-      if (pos == d.target[vid]) atomicExch(&d.cnt->error, TS_E_UNSUPPORTED);  // despawn inside decide (start == goal)
-      early = true;
-    }
-  }
-  if (ev == 2) { base = 0; cur = 0; }  // collision inflicted after this vehicle had decided
-  d.base_speed[vid] = (int8_t)base;
-  d.cur_speed[vid] = (int8_t)cur;
-  d.flags[vid] = early ? (f | VF_EARLY) : f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -706,6 +559,7 @@ __global__ void k_spawn(Dev d, TsParams P, SpawnArgs a, int n, int vid0, int act
   d.base_speed[vid] = 0; d.cur_speed[vid] = 0; d.max_steps[vid] = 0; d.dir[vid] = -1; d.pop[vid] = (int8_t)a.pop[i];
   d.flags[vid] = VF_ALIVE; d.depart[vid] = P.enable_traffic ? elapsed : 0.0;
   d.ev[vid] = 0; d.st_before[vid] = 0; d.st_after[vid] = 0;
+  for (int k = 0; k < 4; k++) { d.ax_len[k][vid] = 0; d.ax_off[k][vid] = 0; d.ax_start[k][vid] = pos; }
   d.active[active0 + i] = vid; d.active_idx[vid] = active0 + i;
   d.sched_kind[sched0 + i] = K_VEHICLE; d.sched_ref[sched0 + i] = vid; d.sched_slot[vid] = sched0 + i;
   d.occ[pos] = 1; d.stuck[pos] = 0;  // place_vehicle (city_model.py:1897-1918)
@@ -847,22 +701,32 @@ struct ts_engine {
   std::vector<uint32_t> perm;
   std::vector<void*> allocs;
   // per-kernel HIP-event timing (ts_profile_*)
+  // replanning: work lists, scratch tiers, density state, host-side _path_cache
+  int32_t* replan_list[4] = {nullptr, nullptr, nullptr, nullptr};
+  int cap_replan = 0;
+  ATier tier[3];
+  bool tier_ready[3] = {false, false, false};
+  bool density_valid = false;
+  float *dens_t0 = nullptr, *dens_t1 = nullptr;
+  int32_t* d_status = nullptr;
+  struct CachedPath { std::vector<uint32_t> words; int len; };
+  std::unordered_map<uint64_t, CachedPath> path_cache;
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
   struct ProfRec { int id; int e0, e1; long long items; };
   std::vector<ProfRec> prof_pending;
   size_t ev_used = 0;
-  double prof_ms[8] = {0};
-  long long prof_launches[8] = {0}, prof_items[8] = {0};
+  double prof_ms[12] = {0};
+  long long prof_launches[12] = {0}, prof_items[12] = {0};
 };
 
 namespace {
 
 typedef ts_engine E;
 
-enum { PK_DECIDE_PRE = 0, PK_DECIDE_MAIN, PK_MOVE_CLAIM, PK_MOVE_RESOLVE, PK_COMPACT, PK_EVENT, PK_COUNT };
+enum { PK_DECIDE_PRE = 0, PK_DECIDE_MAIN, PK_MOVE_CLAIM, PK_MOVE_RESOLVE, PK_COMPACT, PK_EVENT, PK_REPLAN, PK_DENSITY, PK_COUNT };
 const char* PK_NAMES[PK_COUNT] = {"k_decide_pre", "k_decide_main", "k_move_claim", "k_move_resolve",
-                                  "k_compact", "k_apply_event"};
+                                  "k_compact", "k_apply_event", "k_decide_replan", "k_density"};
 
 int prof_begin(E* e, int id, long long items) {
   if (!e->prof) return -1;
@@ -936,8 +800,13 @@ int ensure_vehicle_capacity(E* e, int need_v, int need_sched) {
 #define RG(field) { int rc = regrow(e, &d.field, k, (size_t)nc); if (rc) return rc; }
     RG(pos) RG(target) RG(path_len) RG(path_cur) RG(stuck_ticks) RG(cooldown) RG(stranded_left) RG(steps) RG(over_dur)
     RG(det_dur) RG(next_in_cell) RG(active_idx) RG(sched_slot) RG(path_off) RG(base_speed) RG(cur_speed) RG(max_steps)
-    RG(dir) RG(pop) RG(flags) RG(depart) RG(ev) RG(st_before) RG(st_after)
+    RG(dir) RG(pop) RG(flags) RG(depart) RG(ev) RG(st_before) RG(st_after) RG(ev_idx)
+    for (int k = 0; k < 4; k++) { RG(ax_start[k]) RG(ax_off[k]) RG(ax_len[k]) }
 #undef RG
+    { int rc = regrow(e, &e->replan_list[0], 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &e->replan_list[1], 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &e->replan_list[2], 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &e->replan_list[3], 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &d.active, (size_t)e->n_active, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &e->active_alt, 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &d.F, 0, (size_t)nc); if (rc) return rc; }
@@ -982,6 +851,7 @@ int ensure_pool(E* e, size_t need_words) {
   int rc = regrow(e, &e->d.pool, e->pool_used, nc);
   if (rc) return rc;
   e->pool_cap = nc;
+  e->d.pool_cap_words = nc;
   return TS_OK;
 }
 
@@ -995,6 +865,7 @@ int sync_counters(E* e) {  // device counters -> e->C
   e->C.count_completed_internal = c.completed_internal; e->C.count_completed_through = c.completed_through;
   e->C.total_distance_internal = c.dist_internal; e->C.total_distance_through = c.dist_through;
   e->C.total_duration_internal = c.dur_internal; e->C.total_duration_through = c.dur_through;
+  e->C.astar_calls = c.astar_calls; e->C.astar_expansions = c.astar_exp; e->C.astar_relaxations = c.astar_relax;
   return TS_OK;
 }
 
@@ -1014,6 +885,130 @@ int compact(E* e, int which, int n, int* out_n) {
   *out_n = e->hint[0];
   if (which == 0) std::swap(d.active, e->active_alt);
   else { std::swap(d.sched_kind, e->kind_alt); std::swap(d.sched_ref, e->ref_alt); }
+  return TS_OK;
+}
+
+int pool_from_device(E* e) {
+  unsigned long long v = 0;
+  HIPOK(hipMemcpy(&v, &e->d.cnt->pool_used, sizeof(v), hipMemcpyDeviceToHost));
+  e->pool_used = (size_t)std::min<unsigned long long>(v, e->pool_cap);
+  return TS_OK;
+}
+int pool_to_device(E* e) {
+  unsigned long long v = e->pool_used;
+  HIPOK(hipMemcpy(&e->d.cnt->pool_used, &v, sizeof(v), hipMemcpyHostToDevice));
+  return TS_OK;
+}
+
+// scratch tiers for the GPU A*: many small searchers, fewer large ones, a handful that can hold the whole grid
+int ensure_tier(E* e, int t) {
+  if (e->tier_ready[t]) return TS_OK;
+  ATier& T = e->tier[t];
+  const long long N = e->N;
+  const long long caps[3] = {std::min<long long>(N, 2048), std::min<long long>(N, 32768), N};
+  const int slots[3] = {16384, 1024, 4};
+  T.cap = (int)caps[t];
+  T.n_slots = slots[t];
+  uint32_t hs = 1;
+  while (hs < 2ull * (unsigned long long)T.cap) hs <<= 1;
+  T.hsize = hs;
+  T.heap_cap = (int)std::min<long long>(4ll * T.cap, 0x7FFFFFF0ll);
+  const size_t S = (size_t)T.n_slots;
+  HIPOK(dalloc(e, &T.hkey, S * hs)); HIPOK(dalloc(e, &T.hdist, S * hs)); HIPOK(dalloc(e, &T.hcame, S * hs));
+  HIPOK(dalloc(e, &T.hstamp, S * hs));
+  HIPOK(dalloc(e, &T.hf, S * T.heap_cap)); HIPOK(dalloc(e, &T.hg, S * T.heap_cap)); HIPOK(dalloc(e, &T.hs, S * T.heap_cap));
+  HIPOK(dalloc(e, &T.hi, S * T.heap_cap)); HIPOK(dalloc(e, &T.hd, S * T.heap_cap));
+  HIPOK(dalloc(e, &T.cells, S * ((size_t)5 * T.cap + 3 * MAXB)));
+  HIPOK(dalloc(e, &T.slot_epoch, S));
+  HIPOK(hipMemsetAsync(T.hstamp, 0, S * hs * 4, e->stream));
+  HIPOK(hipMemsetAsync(T.slot_epoch, 0, S * 4, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  e->tier_ready[t] = true;
+  return TS_OK;
+}
+
+// density_map as of the last tick start (city_model.py:1853), materialised only when a search may need it
+int ensure_density(E* e, const int8_t* occ_src) {
+  const size_t N = e->N;
+  if (!e->dens_t0) { HIPOK(dalloc(e, &e->dens_t0, N)); HIPOK(dalloc(e, &e->dens_t1, N)); }
+  if (!e->d.density) HIPOK(dalloc(e, &e->d.density, N));
+  const int r = e->P.vehicle_awareness_range;
+  int tok = prof_begin(e, PK_DENSITY, (long long)N);
+  hipLaunchKernelGGL(k_density_pass0, dim3(nblk((long long)N)), dim3(BLK), 0, e->stream, occ_src, e->d.is_road, e->W, e->H, r,
+                     e->dens_t0, e->dens_t1);
+  hipLaunchKernelGGL(k_density_pass1, dim3(nblk((long long)N)), dim3(BLK), 0, e->stream, e->dens_t0, e->dens_t1, e->W, e->H, r,
+                     e->d.density);
+  prof_end(e, tok);
+  return TS_OK;
+}
+
+// garbage-collect / grow the path pool so that at least `need_free` words are available
+int pool_make_room(E* e, size_t need_free) {
+  int rc = pool_from_device(e);
+  if (rc) return rc;
+  if (e->pool_used + need_free <= e->pool_cap && e->pool_used * 4 < e->pool_cap * 3) return TS_OK;
+  // copy the live words of every active vehicle into a fresh pool (twice as large if it was mostly live)
+  size_t new_cap = e->pool_cap;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (new_cap >= (1ull << 32)) return fail(e, TS_E_CAPACITY, "path pool exceeds 2^32 words");
+    uint32_t* np = nullptr;
+    unsigned long long* used = nullptr;
+    HIPOK(dalloc(e, &np, new_cap));
+    HIPOK(dalloc(e, &used, 1));
+    HIPOK(hipMemsetAsync(used, 0, sizeof(unsigned long long), e->stream));
+    // the GC kernel rewrites offsets in place, so it can only run once per pool: size the target generously
+    if (attempt == 0 && e->pool_used * 2 > new_cap) { dfree(e, np); dfree(e, used); new_cap = std::min<size_t>(new_cap * 2, (1ull << 32) - 1); continue; }
+    if (e->n_active > 0)
+      hipLaunchKernelGGL(k_pool_gc, dim3(nblk(e->n_active)), dim3(BLK), 0, e->stream, e->d, e->n_active, np, used);
+    unsigned long long u = 0;
+    HIPOK(hipMemcpyAsync(&u, used, sizeof(u), hipMemcpyDeviceToHost, e->stream));
+    HIPOK(hipStreamSynchronize(e->stream));
+    dfree(e, e->d.pool);
+    dfree(e, used);
+    e->d.pool = np; e->pool_cap = new_cap; e->d.pool_cap_words = new_cap; e->pool_used = (size_t)u;
+    rc = pool_to_device(e);
+    if (rc) return rc;
+    break;
+  }
+  if (e->pool_used + need_free > e->pool_cap) {
+    rc = ensure_pool(e, (e->pool_used + need_free) * 2);
+    if (rc) return rc;
+  }
+  return TS_OK;
+}
+
+// k_decide_replan over the work lists: tier 0 -> overflow to tier 1 -> tier 2; pool-full entries are retried
+int run_replans(E* e, int n0) {
+  Dev& d = e->d;
+  const TsParams& P = e->P;
+  hipStream_t st = e->stream;
+  while (n0 > 0) {
+    if (!e->density_valid) { int rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
+    int n = n0;
+    for (int t = 0; t < 3 && n > 0; t++) {
+      int rc = ensure_tier(e, t);
+      if (rc) return rc;
+      d.density = e->d.density;
+      const ATier& T = e->tier[t];
+      for (int begin = 0; begin < n; begin += T.n_slots) {
+        int cnt = std::min(T.n_slots, n - begin);
+        LAUNCH(e, PK_REPLAN, cnt, k_decide_replan, dim3(nblk(cnt, 64)), dim3(64), d, P, T, e->replan_list[t], begin, cnt,
+               t < 2 ? e->replan_list[t + 1] : e->replan_list[3], t < 2 ? t + 1 : 4, e->replan_list[3]);
+      }
+      HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+      HIPOK(hipStreamSynchronize(st));
+      if (e->hint[8 + 4] > 0) return fail(e, TS_E_CAPACITY, "an A* search exceeded the largest scratch tier");
+      n = t < 2 ? e->hint[8 + t + 1] : 0;
+    }
+    int retry = e->hint[8 + 3];
+    if (retry == 0) break;
+    // the path pool filled up: make room (GC, then growth) and run the entries that could not commit again
+    int rc = pool_make_room(e, (size_t)retry * 1024 + (1u << 20));
+    if (rc) return rc;
+    HIPOK(hipMemcpyAsync(e->replan_list[0], e->replan_list[3], (size_t)retry * 4, hipMemcpyDeviceToDevice, st));
+    HIPOK(hipMemsetAsync(d.cnt->replan_n, 0, sizeof(int) * 6, st));
+    n0 = retry;
+  }
   return TS_OK;
 }
 
@@ -1039,9 +1034,13 @@ int tick(E* e) {
   std::thread shuffler([e, nS]() { shuffle_ranks(e, nS); });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{shuffler};
 
+  // density_map is a function of the occupancy at this point (city_model.py:1853)
+  HIPOK(hipMemcpyAsync(d.occ_snap, d.occ, (size_t)e->N, hipMemcpyDeviceToDevice, st));
+  e->density_valid = false;
   // ---------------- decide ----------------
   if (nA > 0) {
     HIPOK(hipMemsetAsync(d.ev, 0, (size_t)e->n_vehicles_total, st));
+    HIPOK(hipMemsetAsync(d.cnt->replan_n, 0, sizeof(int) * 6, st));
     int start = 0;
     int i = 0;
     memset(e->hR, 0, nA);
@@ -1081,7 +1080,10 @@ int tick(E* e) {
       start = i;
     }
     HIPOK(hipMemcpyAsync(d.R, e->hR, nA, hipMemcpyHostToDevice, st));
-    LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA);
+    LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, e->replan_list[0]);
+    HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    if (e->hint[8] > 0) { int rc = run_replans(e, e->hint[8]); if (rc) return rc; }
   }
 
   // ---------------- move (schedule.step) ----------------
@@ -1117,7 +1119,6 @@ int tick(E* e) {
       chunk = 4;
     }
     if (e->hint[3]) return fail(e, e->hint[3], "device-side error: a vehicle sits on its target during decide (start == goal is not supported)");
-    if (e->hint[2]) return fail(e, TS_E_UNSUPPORTED, "a vehicle requested a replan but the GPU A* is not built yet");
     e->C.agent_steps += e->n_sched_vehicles;
     const int deaths = e->hint[1];
     if (deaths > 0) {
@@ -1187,7 +1188,7 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
 #define A(ptr, n) if (dalloc(e, &ptr, (size_t)(n)) != hipSuccess) return bail(TS_E_DEVICE);
   A(d.occ, N) A(d.stop, N) A(d.stuck, N) A(d.rain, N) A(d.allowed, N) A(d.is_road, N) A(d.road_type, N) A(d.inter, N)
   A(d.cell_veh, N) A(d.cw_occ, N) A(d.cr_occ, N) A(d.cw_stop, N) A(d.cr_stop, N) A(d.gclaim_r, 1)
-  A(d.cnt, 1) A(e->d_total, 1) A(e->d_crc, 256)
+  A(d.cnt, 1) A(e->d_total, 1) A(e->d_crc, 256) A(d.occ_snap, N) A(e->d_status, 4)
 #undef A
   hipStream_t st = e->stream;
   bool ok = true;
@@ -1195,6 +1196,7 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   ok &= hipMemsetAsync(d.stop, 0, N, st) == hipSuccess;
   ok &= hipMemsetAsync(d.stuck, 0, N, st) == hipSuccess;
   ok &= hipMemsetAsync(d.rain, 0, N, st) == hipSuccess;
+  ok &= hipMemsetAsync(d.occ_snap, 0, N, st) == hipSuccess;  // _update_density_map() on the fresh, empty model
   ok &= hipMemsetAsync(d.cell_veh, 0xFF, N * 4, st) == hipSuccess;
   ok &= hipMemsetAsync(d.cnt, 0, sizeof(DevCnt), st) == hipSuccess;
   ok &= hipMemcpyAsync(d.allowed, w->allowed_dirs_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
@@ -1361,6 +1363,10 @@ static int add_vehicles_core(ts_handle e, int n, std::vector<int32_t>& start, st
                              std::vector<int32_t>& pop, std::vector<int32_t>& plen, std::vector<uint32_t>& poff,
                              std::vector<uint32_t>& enc) {
   const size_t words = enc.size();
+  {
+    int rc0 = pool_make_room(e, words + 1);
+    if (rc0) return rc0;
+  }
   for (int i = 0; i < n; i++) poff[i] += (uint32_t)e->pool_used;
   // start cells shared inside the batch must be appended to the cell list in spawn order
   std::vector<uint8_t> serial(n, 0);
@@ -1413,8 +1419,70 @@ static int add_vehicles_core(ts_handle e, int n, std::vector<int32_t>& start, st
     HIPOK(hipMemcpy(e->d.cnt, e->hcnt, sizeof(DevCnt), hipMemcpyHostToDevice));
   }
   e->pool_used += words;
+  rc = pool_to_device(e);
+  if (rc) return rc;
   e->n_vehicles_total += n; e->n_active += n; e->n_sched += n; e->n_sched_vehicles += n;
   return TS_OK;
+}
+
+// VehicleAgent.__init__ for one vehicle whose path the engine plans itself: place_vehicle, then
+// self.path = self._compute_path() with city._path_cache (vehicle_base.py:78-81, 143-167)
+static int add_vehicle_planned(ts_handle e, int start, int goal, int pop_type) {
+  std::vector<int32_t> s1{start}, g1{goal}, p1{pop_type}, l1{0};
+  std::vector<uint32_t> o1{0}, enc;
+  int rc = add_vehicles_core(e, 1, s1, g1, p1, l1, o1, enc);
+  if (rc) return rc;
+  const int vid = e->n_vehicles_total - 1;
+  const uint64_t key = ((uint64_t)(uint32_t)start << 32) | (uint32_t)goal;
+  Dev& d = e->d;
+  if (e->P.pathfinding_cache) {
+    auto it = e->path_cache.find(key);
+    if (it != e->path_cache.end()) {
+      const auto& cp = it->second;
+      rc = pool_make_room(e, cp.words.size() + 1);
+      if (rc) return rc;
+      uint32_t off = (uint32_t)e->pool_used;
+      int len = cp.len, zero = 0;
+      if (!cp.words.empty()) HIPOK(hipMemcpy(d.pool + off, cp.words.data(), cp.words.size() * 4, hipMemcpyHostToDevice));
+      HIPOK(hipMemcpy(d.path_off + vid, &off, 4, hipMemcpyHostToDevice));
+      HIPOK(hipMemcpy(d.path_len + vid, &len, 4, hipMemcpyHostToDevice));
+      HIPOK(hipMemcpy(d.path_cur + vid, &zero, 4, hipMemcpyHostToDevice));
+      e->pool_used += cp.words.size();
+      return pool_to_device(e);
+    }
+  }
+  if (!e->density_valid) { rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
+  for (int t = 0; t < 3; t++) {
+    rc = ensure_tier(e, t);
+    if (rc) return rc;
+    for (int attempt = 0; attempt < 3; attempt++) {
+      hipLaunchKernelGGL(k_spawn_plan, dim3(1), dim3(64), 0, e->stream, d, e->P, e->tier[t], vid, e->d_status);
+      HIPOK(hipMemcpyAsync(e->hint, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+      HIPOK(hipStreamSynchronize(e->stream));
+      if (e->hint[0] != -2) break;
+      rc = pool_make_room(e, (size_t)e->tier[t].cap + (1u << 16));  // pool full: make room and plan again
+      if (rc) return rc;
+    }
+    if (e->hint[0] == -2) return fail(e, TS_E_CAPACITY, "path pool exhausted while planning a spawn");
+    if (e->hint[0] >= 0) {
+      const int len = e->hint[0];
+      rc = pool_from_device(e);
+      if (rc) return rc;
+      uint16_t fl = 0;
+      HIPOK(hipMemcpy(&fl, d.flags + vid, 2, hipMemcpyDeviceToHost));
+      if (e->P.pathfinding_cache && len > 0 && !(fl & (VF_OVER | VF_DETOUR))) {
+        ts_engine::CachedPath cp;
+        cp.len = len;
+        cp.words.resize((size_t)(len + 15) / 16);
+        uint32_t off = 0;
+        HIPOK(hipMemcpy(&off, d.path_off + vid, 4, hipMemcpyDeviceToHost));
+        HIPOK(hipMemcpy(cp.words.data(), d.pool + off, cp.words.size() * 4, hipMemcpyDeviceToHost));
+        e->path_cache[key] = std::move(cp);
+      }
+      return TS_OK;
+    }
+  }
+  return fail(e, TS_E_CAPACITY, "an A* search exceeded the largest scratch tier");
 }
 
 static int add_vehicles_any(ts_handle e, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
@@ -1422,9 +1490,20 @@ static int add_vehicles_any(ts_handle e, int32_t n, const int32_t* start_xy, con
                             const int64_t* off64, const uint8_t* path_dirs) {
   if (!e || n < 0 || (n > 0 && (!start_xy || !goal_xy))) return TS_E_INVALID;
   if (n == 0) return TS_OK;
-  if (!(off32 && path_xy) && !(off64 && path_dirs))
-    return fail(e, TS_E_UNSUPPORTED, "initial paths must be supplied until the GPU A* is built");
   const int W = e->W, H = e->H;
+  if (!(off32 && path_xy) && !(off64 && path_dirs)) {
+    // the reference's own path: each vehicle is placed, then plans on the maps as they are at that moment
+    for (int i = 0; i < n; i++) {
+      int sx = start_xy[2 * i], sy = start_xy[2 * i + 1], gx = goal_xy[2 * i], gy = goal_xy[2 * i + 1];
+      if (sx < 0 || sx >= W || sy < 0 || sy >= H || gx < 0 || gx >= W || gy < 0 || gy >= H)
+        return fail(e, TS_E_INVALID, "vehicle start/goal out of bounds");
+      if (sx == gx && sy == gy) return fail(e, TS_E_UNSUPPORTED, "start == goal (vehicle despawns inside the decide phase)");
+      if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
+      int rc = add_vehicle_planned(e, sy * W + sx, gy * W + gx, population_type ? population_type[i] : TS_POP_UNDEFINED);
+      if (rc) return rc;
+    }
+    return TS_OK;
+  }
   if ((long long)e->n_sched + n >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
   std::vector<int32_t> start(n), goal(n), pop(n), plen(n);
   std::vector<uint32_t> poff(n);
@@ -1610,8 +1689,32 @@ int ts_profile_get(ts_handle e, int32_t id, double* total_ms, int64_t* launches,
   return TS_OK;
 }
 
-int ts_astar(ts_handle e, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t*, int32_t) {
-  return fail(e, TS_E_UNSUPPORTED, "GPU A* is not built yet");
+int ts_astar(ts_handle e, int32_t sx, int32_t sy, int32_t gx, int32_t gy, int32_t soft, int32_t ignore_flow,
+             int32_t maximum_steps, int32_t* out_xy, int32_t cap_cells) {
+  if (!e) return TS_E_INVALID;
+  if (sx < 0 || sx >= e->W || sy < 0 || sy >= e->H || gx < 0 || gx >= e->W || gy < 0 || gy >= e->H)
+    return fail(e, TS_E_INVALID, "astar endpoints out of bounds");
+  int rc = ensure_density(e, e->d.occ);  // "evaluated on the engine's current maps"
+  if (rc) return rc;
+  e->density_valid = false;
+  for (int t = 0; t < 3; t++) {
+    rc = ensure_tier(e, t);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_astar_single, dim3(1), dim3(64), 0, e->stream, e->d, e->P, e->tier[t], sy * e->W + sx,
+                       gy * e->W + gx, soft, ignore_flow, maximum_steps, e->d_status);
+    HIPOK(hipMemcpyAsync(e->hint, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPOK(hipStreamSynchronize(e->stream));
+    int len = e->hint[0];
+    if (len < 0) continue;
+    if (len > cap_cells) return TS_E_CAPACITY;
+    if (len > 0) {
+      std::vector<int32_t> cells(len);
+      HIPOK(hipMemcpy(cells.data(), e->tier[t].cells, (size_t)len * 4, hipMemcpyDeviceToHost));
+      for (int k = 0; k < len; k++) { out_xy[2 * k] = cells[k] % e->W; out_xy[2 * k + 1] = cells[k] / e->W; }
+    }
+    return len;
+  }
+  return fail(e, TS_E_CAPACITY, "an A* search exceeded the largest scratch tier");
 }
 
 }  // extern "C"
