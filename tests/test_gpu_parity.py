@@ -142,3 +142,9 @@ def test_hip_vs_oracle_full_size_4096_1m():
     """BASELINE.json's headline size (4096x4096, 10^6 vehicles), 6 ticks, compared state for state."""
     h, c = _pair(4096, 1_000_000, 1, {})
     _compare(h, c, 6, every=3)
+
+
+def test_facade_on_hip(hip):
+    """The Mesa-shaped facade (CityModel / VehicleAgent / grid / schedule) over the HIP engine."""
+    from tests.test_mesa_facade import run_facade_against_trace
+    run_facade_against_trace(hip)

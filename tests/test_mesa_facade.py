@@ -1,0 +1,70 @@
+"""The Mesa-shaped facade: same names / argument meaning as the reference's CityModel,
+VehicleAgent, CellAgent, schedule and grid.  Driven here over the CPU oracle so the host logic is covered
+without a GPU; tests/test_gpu_parity.py::test_facade_on_hip runs the same check on the HIP engine."""
+import numpy as np
+import pytest
+
+from trafficsimulation_amd import _capi as capi
+from trafficsimulation_amd.mesa_api import CityModel, VehicleAgent, agent_portrayal
+from trafficsimulation_amd.world import load_trace
+from tests.trace_util import trace_path
+
+
+def run_facade_against_trace(engine, name="lights_qa_96_s2", ticks=30):
+    tr = load_trace(trace_path(name))
+    m = CityModel.from_tables(tr, seed=1, defaults=tr["defaults_json"], engine=engine,
+                              global_state=tr["global_rng_after_worldgen"], sched_state=tr["sched_rng_initial"])
+    assert (m.width, m.height) == (int(tr["width"]), int(tr["height"]))
+    vehicles = []
+    for i, (s, g) in enumerate(zip(tr["v_start_xy"], tr["v_goal_xy"])):
+        v = VehicleAgent(f"gv_{i}", m, m.cell(int(s[0]), int(s[1])), m.cell(int(g[0]), int(g[1])), population_type="through")
+        vehicles.append(v)
+    assert len(m.active_vehicle_agents) == len(vehicles)
+    assert len(m.schedule.agents) == len(m.intersection_light_groups) + 1 + len(vehicles)
+    H, W = m.height, m.width
+    fields = tr["veh_fields"]
+    for t in range(ticks):
+        m.step()
+        want = tr["veh_rows"][tr["veh_off"][t]:tr["veh_off"][t + 1]]
+        live = m.active_vehicle_agents
+        assert [v._spawn_idx for v in live] == list(want[:, 0])
+        for v, r in zip(live[::7], want[::7]):
+            assert v.pos == (r[1], r[2])
+            assert v.current_speed == r[fields.index("current_speed")]
+            assert (v.direction is None) == (r[fields.index("direction")] < 0)
+            assert v.get_portrayal()["Position"] == v.pos
+        occ = np.unpackbits(tr["occ_t"][t])[:H * W].reshape(H, W)
+        assert np.array_equal(m.occupancy_map, occ)
+        assert np.array_equal(m.stop_map, np.unpackbits(tr["stop_t"][t])[:H * W].reshape(H, W))
+    assert m.step_count == ticks
+    # MultiGrid view: the static cell first, then the vehicles standing there
+    v = m.active_vehicle_agents[0]
+    x, y = v.pos
+    contents = m.grid[x, y]
+    assert contents[0] is m.cell(x, y) and v in contents[1:]
+    assert m.get_cell_contents(-1, 0) == []
+    # removed vehicles report pos None like MultiGrid.remove_agent
+    gone = [v for v in vehicles if v not in m.active_vehicle_agents]
+    assert all(g.pos is None for g in gone)
+    # light-group views and the UI's direct writes (cell.py:241-251) reach the engine before the next tick
+    g0 = m.intersection_light_groups[0]
+    assert g0.current_phase in (0, 1) and g0.pending_phase in (None, 0, 1)
+    g0.set_all_stop()
+    for tl in g0.traffic_lights:
+        assert m.stop_map[tl.position[1], tl.position[0]] == 1
+        for cb in tl.controlled_blocks:
+            assert m.stop_map[cb.position[1], cb.position[0]] == 1
+    m.schedule.step()
+    assert agent_portrayal(m.traffic_lights[0])["Shape"] == "rect"
+    stats = m.dynamic_traffic_generator.cached_stats
+    assert stats["live_through"] == len(m.active_vehicle_agents)
+    with pytest.raises(NotImplementedError):
+        v.step()
+    # duplicate ids are rejected like the Mesa scheduler does
+    with pytest.raises(Exception):
+        VehicleAgent("gv_0", m, m.cell(*map(int, tr["v_start_xy"][0])), m.cell(*map(int, tr["v_goal_xy"][0])))
+    return m
+
+
+def test_facade_over_oracle(oracle):
+    run_facade_against_trace(oracle)
