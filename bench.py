@@ -135,6 +135,7 @@ def main():
     if rank == 0:
         total_ms = {k: v[0] for k, v in prof.items()}
         dom = max((k for k in total_ms if ALGO_BYTES.get(k, 0) > 0), key=lambda k: total_ms[k])
+        host_keys = [k for k in prof if k.startswith("host_")]
         ms, launches, items = prof[dom]
         # algorithmic bytes per launch: per-unit figure x vehicles stepped, spread over this kernel's launches
         veh_steps_local = c1.agent_steps - c0.agent_steps
@@ -160,8 +161,8 @@ def main():
                 "algorithmic_bytes_per_agent_step": ALGO_BYTES[dom], "avg_launch_us": avg_launch_s * 1e6,
                 "launches": launches,
             },
-            "kernels_ms_per_tick": {k: v[0] / args.steps for k, v in prof.items()},
-            "host_ms_per_tick": elapsed / args.steps * 1e3 - sum(v[0] for v in prof.values()) / args.steps,
+            "kernels_ms_per_tick": {k: v[0] / args.steps for k, v in prof.items() if not k.startswith("host_")},
+            "host_ms_per_tick": {k: prof[k][0] / args.steps for k in host_keys},
             "setup_seconds": {"citygen": gen_t[0], "routes": gen_t[1]},
         }
     api.close()

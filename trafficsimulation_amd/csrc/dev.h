@@ -31,6 +31,8 @@ struct DevCnt {
   int replan_n[6]; // work-list lengths: tier 0, tier 1, tier 2, pool-full retries, beyond the last tier, pad
   unsigned long long pool_used;  // words handed out from the path pool (device-side bump allocator)
   long long astar_calls, astar_exp, astar_relax;
+  int pend_n[2];   // lengths of the two ping-pong lists of still-unresolved schedule slots
+  int pad_[2];
 };
 
 struct Dev {
@@ -71,7 +73,9 @@ struct Dev {
   int32_t *gs_cur, *gs_pend, *gs_trans, *gs_clear, *gs_ftphase, *gs_fttimer, *gs_qtimer, *gs_gap, *gs_last, *gs_nsp,
       *gs_ewp, *gs_repop;
   // per-cell min-rank claims for the move phase (epoch-tagged so they never need clearing)
-  uint32_t *cw_occ, *cr_occ, *cw_stop, *cr_stop, *gclaim_r;
+  // the four claim words of a cell are adjacent (one 16-byte record per cell): plane 0 = writers of occupancy,
+  // 1 = readers of occupancy, 2 = writers of stop, 3 = readers of stop
+  uint32_t *claims, *gclaim_r;
   // decide-phase exchange buffers
   uint8_t *F, *R;
   int32_t* cand;

@@ -20,6 +20,9 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <chrono>
+#include <mutex>
+#include <condition_variable>
 #include <unordered_map>
 #include <vector>
 
@@ -143,9 +146,12 @@ __device__ __forceinline__ bool group_reads_neighbors(const TsParams& P) {
 // Every unresolved agent announces the cells it will read/write: cw_* = min rank of writers,
 // cr_* = min rank of readers.  Keys carry an epoch prefix that DEcreases every round, so atomicMin
 // makes stale entries of earlier rounds lose and nothing has to be cleared.
-__global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_sched || d.resolved[s]) return;
+// `list` == nullptr: every schedule slot (first round); otherwise the slots left unresolved by the previous round.
+__global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix, const int32_t* list, const int* list_n) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int s;
+  if (list) { if (t >= *list_n) return; s = list[t]; } else { s = t; if (s >= n_sched) return; }
+  if (d.resolved[s]) return;
   const int8_t kind = d.sched_kind[s];
   const uint32_t key = (prefix << RANK_BITS) | d.rank[s];
   if (kind == K_VEHICLE) {
@@ -153,32 +159,32 @@ __global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix) {
     const uint16_t f = d.flags[vid];
     const int pos = d.pos[vid];
     if (f & VF_EARLY) {
-      if (d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED) claim(d.cr_stop, pos, key);  // tick_stuck reads stop[pos]
-      if (pos == d.target[vid]) claim(d.cw_occ, pos, key);
+      if (d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED) claim(d.claims, (pos) * 4 + 3, key);  // tick_stuck reads stop[pos]
+      if (pos == d.target[vid]) claim(d.claims, (pos) * 4 + 0, key);
     } else {
       const int m = d.max_steps[vid];
-      claim(d.cw_occ, pos, key);
+      claim(d.claims, (pos) * 4 + 0, key);
       const uint32_t off = d.path_off[vid];
       const int pcur = d.path_cur[vid];
       int c = pos;
       for (int k = 0; k < m; k++) {
         c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
-        claim(d.cw_occ, c, key);
-        if (d.G > 0) claim(d.cr_stop, c, key);
+        claim(d.claims, (c) * 4 + 0, key);
+        if (d.G > 0) claim(d.claims, (c) * 4 + 3, key);
       }
     }
   } else if (kind == TS_AGENT_LIGHT_GROUP && P.light_algorithm != TS_LIGHTS_DISABLED) {
     const int g = d.sched_ref[s];
-    for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1]; k++) claim(d.cr_occ, d.g_icell[k], key);
-    for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1]; k++) claim(d.cr_occ, d.g_nsin[k], key);
-    for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1]; k++) claim(d.cr_occ, d.g_ewin[k], key);
+    for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1]; k++) claim(d.claims, (d.g_icell[k]) * 4 + 1, key);
+    for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1]; k++) claim(d.claims, (d.g_nsin[k]) * 4 + 1, key);
+    for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1]; k++) claim(d.claims, (d.g_ewin[k]) * 4 + 1, key);
     if (group_reads_out(P)) {
-      for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1]; k++) claim(d.cr_occ, d.g_nsout[k], key);
-      for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1]; k++) claim(d.cr_occ, d.g_ewout[k], key);
+      for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1]; k++) claim(d.claims, (d.g_nsout[k]) * 4 + 1, key);
+      for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1]; k++) claim(d.claims, (d.g_ewout[k]) * 4 + 1, key);
     }
     for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1]; l++) {
-      claim(d.cw_stop, d.light_cell[l], key);
-      for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) claim(d.cw_stop, d.light_ctrl[k], key);
+      claim(d.claims, (d.light_cell[l]) * 4 + 2, key);
+      for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) claim(d.claims, (d.light_ctrl[k]) * 4 + 2, key);
     }
     if (group_reads_neighbors(P)) {
       for (int k = 0; k < 4; k++) {
@@ -389,9 +395,12 @@ __device__ void group_step_dev(const Dev& d, const TsParams& P, int g) {
 }
 
 // An agent steps in this round iff no unresolved agent of lower rank claims a cell it reads or writes.
-__global__ void k_move_resolve(Dev d, TsParams P, int n_sched, uint32_t prefix, uint32_t rank_clock, double elapsed0) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_sched || d.resolved[s]) return;
+__global__ void k_move_resolve(Dev d, TsParams P, int n_sched, uint32_t prefix, uint32_t rank_clock, double elapsed0,
+                               const int32_t* list, const int* list_n, int32_t* out_list, int* out_n) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int s;
+  if (list) { if (t >= *list_n) return; s = list[t]; } else { s = t; if (s >= n_sched) return; }
+  if (d.resolved[s]) return;
   const int8_t kind = d.sched_kind[s];
   const uint32_t r = d.rank[s];
   bool safe = true;
@@ -401,43 +410,43 @@ __global__ void k_move_resolve(Dev d, TsParams P, int n_sched, uint32_t prefix, 
     const int pos = d.pos[vid];
     const bool lights = d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED;
     if (f & VF_EARLY) {
-      if (lights && claim_rank(d.cw_stop[pos], prefix) < r) safe = false;
-      if (pos == d.target[vid] && (claim_rank(d.cw_occ[pos], prefix) < r || claim_rank(d.cr_occ[pos], prefix) < r))
+      if (lights && claim_rank(d.claims[(pos) * 4 + 2], prefix) < r) safe = false;
+      if (pos == d.target[vid] && (claim_rank(d.claims[(pos) * 4 + 0], prefix) < r || claim_rank(d.claims[(pos) * 4 + 1], prefix) < r))
         safe = false;
     } else {
       const int m = d.max_steps[vid];
-      if (claim_rank(d.cw_occ[pos], prefix) < r || claim_rank(d.cr_occ[pos], prefix) < r) safe = false;
+      if (claim_rank(d.claims[(pos) * 4 + 0], prefix) < r || claim_rank(d.claims[(pos) * 4 + 1], prefix) < r) safe = false;
       const uint32_t off = d.path_off[vid];
       const int pcur = d.path_cur[vid];
       int c = pos;
       for (int k = 0; k < m && safe; k++) {
         c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
-        if (claim_rank(d.cw_occ[c], prefix) < r || claim_rank(d.cr_occ[c], prefix) < r) safe = false;
-        if (lights && claim_rank(d.cw_stop[c], prefix) < r) safe = false;
+        if (claim_rank(d.claims[(c) * 4 + 0], prefix) < r || claim_rank(d.claims[(c) * 4 + 1], prefix) < r) safe = false;
+        if (lights && claim_rank(d.claims[(c) * 4 + 2], prefix) < r) safe = false;
       }
     }
-    if (!safe) return;
+    if (!safe) { out_list[atomicAdd(out_n, 1)] = s; return; }
     vehicle_step_dev(d, P, vid, s, elapsed0 + (r > rank_clock ? (double)P.time_per_step_seconds : 0.0));
   } else if (kind == TS_AGENT_LIGHT_GROUP && P.light_algorithm != TS_LIGHTS_DISABLED) {
     const int g = d.sched_ref[s];
     for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1] && safe; k++)
-      if (claim_rank(d.cw_occ[d.g_icell[k]], prefix) < r) safe = false;
+      if (claim_rank(d.claims[(d.g_icell[k]) * 4 + 0], prefix) < r) safe = false;
     for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1] && safe; k++)
-      if (claim_rank(d.cw_occ[d.g_nsin[k]], prefix) < r) safe = false;
+      if (claim_rank(d.claims[(d.g_nsin[k]) * 4 + 0], prefix) < r) safe = false;
     for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1] && safe; k++)
-      if (claim_rank(d.cw_occ[d.g_ewin[k]], prefix) < r) safe = false;
+      if (claim_rank(d.claims[(d.g_ewin[k]) * 4 + 0], prefix) < r) safe = false;
     if (group_reads_out(P)) {
       for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1] && safe; k++)
-        if (claim_rank(d.cw_occ[d.g_nsout[k]], prefix) < r) safe = false;
+        if (claim_rank(d.claims[(d.g_nsout[k]) * 4 + 0], prefix) < r) safe = false;
       for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1] && safe; k++)
-        if (claim_rank(d.cw_occ[d.g_ewout[k]], prefix) < r) safe = false;
+        if (claim_rank(d.claims[(d.g_ewout[k]) * 4 + 0], prefix) < r) safe = false;
     }
     for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1] && safe; l++) {
       int lc = d.light_cell[l];
-      if (claim_rank(d.cw_stop[lc], prefix) < r || claim_rank(d.cr_stop[lc], prefix) < r) safe = false;
+      if (claim_rank(d.claims[(lc) * 4 + 2], prefix) < r || claim_rank(d.claims[(lc) * 4 + 3], prefix) < r) safe = false;
       for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1] && safe; k++) {
         int cc = d.light_ctrl[k];
-        if (claim_rank(d.cw_stop[cc], prefix) < r || claim_rank(d.cr_stop[cc], prefix) < r) safe = false;
+        if (claim_rank(d.claims[(cc) * 4 + 2], prefix) < r || claim_rank(d.claims[(cc) * 4 + 3], prefix) < r) safe = false;
       }
     }
     if (safe && group_reads_neighbors(P)) {
@@ -451,7 +460,7 @@ __global__ void k_move_resolve(Dev d, TsParams P, int n_sched, uint32_t prefix, 
       }
       if (claim_rank(d.gclaim_r[g], prefix) < r) safe = false;  // a lower-ranked group still has to read mine
     }
-    if (!safe) return;
+    if (!safe) { out_list[atomicAdd(out_n, 1)] = s; return; }
     group_step_dev(d, P, g);
   }
   d.resolved[s] = 1;
@@ -648,6 +657,12 @@ __global__ void k_density_pass1(const float* t_occ, const float* t_road, int W, 
   density[i] = v1 > 0.f ? __fdiv_rn(v0, v1) : 0.f;
 }
 
+// rank[slot] = position of the slot in the shuffled key order
+__global__ void k_rank_invert(const uint32_t* perm, uint32_t* rank, int n) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) rank[perm[q]] = (uint32_t)q;
+}
+
 template <typename T>
 __global__ void k_fill(T* p, T v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -694,11 +709,18 @@ struct ts_engine {
   int* hint = nullptr;
   int cap_host = 0;
   // RNG streams (host)
-  HostMT rng_global, rng_sched;
-  bool seeded[2] = {false, false};
+  MTPipe rng_global, rng_sched;   // word streams pre-generated by producer threads
+  uint32_t* d_perm = nullptr;     // shuffled key order (perm[q] = slot stepping at time q)
+  uint32_t rank_clock_host = 0xFFFFFFFFu;
   uint32_t epoch = 0;
   TsCounters C;
-  std::vector<uint32_t> perm;
+  std::vector<uint32_t> perm, shuffle_j;
+  int32_t* pend_list[2] = {nullptr, nullptr};
+  std::thread sh_thread;
+  std::mutex sh_mu;
+  std::condition_variable sh_cv;
+  bool sh_req = false, sh_done = true, sh_quit = false;
+  int sh_n = 0;
   std::vector<void*> allocs;
   // per-kernel HIP-event timing (ts_profile_*)
   // replanning: work lists, scratch tiers, density state, host-side _path_cache
@@ -716,17 +738,19 @@ struct ts_engine {
   struct ProfRec { int id; int e0, e1; long long items; };
   std::vector<ProfRec> prof_pending;
   size_t ev_used = 0;
-  double prof_ms[12] = {0};
-  long long prof_launches[12] = {0}, prof_items[12] = {0};
+  double prof_ms[16] = {0};
+  long long prof_launches[16] = {0}, prof_items[16] = {0};
+  double shuffle_ms = 0;
 };
 
 namespace {
 
 typedef ts_engine E;
 
-enum { PK_DECIDE_PRE = 0, PK_DECIDE_MAIN, PK_MOVE_CLAIM, PK_MOVE_RESOLVE, PK_COMPACT, PK_EVENT, PK_REPLAN, PK_DENSITY, PK_COUNT };
+enum { PK_DECIDE_PRE = 0, PK_DECIDE_MAIN, PK_MOVE_CLAIM, PK_MOVE_RESOLVE, PK_COMPACT, PK_EVENT, PK_REPLAN, PK_DENSITY, PH_SCAN, PH_SHUFFLE, PH_SHUFFLE_WAIT, PH_DECIDE_WALL, PH_MOVE_WALL, PK_COUNT };
 const char* PK_NAMES[PK_COUNT] = {"k_decide_pre", "k_decide_main", "k_move_claim", "k_move_resolve",
-                                  "k_compact", "k_apply_event", "k_decide_replan", "k_density"};
+                                  "k_compact", "k_apply_event", "k_decide_replan", "k_density",
+                                  "host_rng_scan", "host_shuffle", "host_shuffle_wait", "host_decide_wall", "host_move_wall"};
 
 int prof_begin(E* e, int id, long long items) {
   if (!e->prof) return -1;
@@ -820,6 +844,9 @@ int ensure_vehicle_capacity(E* e, int need_v, int need_sched) {
     { int rc = regrow(e, &d.sched_kind, (size_t)e->n_sched, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &d.sched_ref, (size_t)e->n_sched, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &d.rank, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &e->d_perm, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &e->pend_list[0], 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &e->pend_list[1], 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &d.resolved, 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &e->kind_alt, 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &e->ref_alt, 0, (size_t)nc); if (rc) return rc; }
@@ -1012,17 +1039,96 @@ int run_replans(E* e, int n0) {
   return TS_OK;
 }
 
-// random.shuffle(keys) with model.random, then rank[slot] = position in the shuffled order (A4)
+// random.shuffle(keys) with model.random: Fisher-Yates from the top with _randbelow's
+// rejection sampling, reading pre-generated words.  Leaves perm[q] = schedule slot stepping at time q in the
+// pinned buffer e->hrank (inverted to rank[slot] on the device) and the clock agent's rank in rank_clock_host.
 void shuffle_ranks(E* e, int n) {
   e->perm.resize(n);
-  uint32_t* p = e->perm.data();
+  uint32_t* p = e->perm.data();  // ordinary cached memory, first touched by this thread
   for (int i = 0; i < n; i++) p[i] = (uint32_t)i;
-  HostMT& r = e->rng_sched;
-  for (int i = n - 1; i >= 1; i--) {
-    uint32_t j = r.randbelow((uint32_t)(i + 1));
-    uint32_t t = p[i]; p[i] = p[j]; p[j] = t;
+  MTPipe& r = e->rng_sched;
+  uint64_t w = r.pos();
+  const uint32_t cs = e->clock_slot >= 0 ? (uint32_t)e->clock_slot : 0xFFFFFFFFu;
+  uint32_t cpos = cs;
+  const int CH = 1 << 12;
+  e->shuffle_j.resize(CH);
+  uint32_t* jb = e->shuffle_j.data();
+  for (int hi = n - 1; hi >= 1; hi -= CH) {
+    const int lo = std::max(1, hi - CH + 1);
+    r.need((uint64_t)(hi - lo + 1) * 4 + 512 + (w - r.pos()));
+    uint64_t limit = w + (uint64_t)(hi - lo + 1) * 4 + 256;
+    // pass A: the draws depend only on the word stream.  Walk the WORDS in order (addresses are not data
+    // dependent, so the loads pipeline): a word is the draw of the current element if it is below i + 1,
+    // otherwise it is a rejected try.  The only loop-carried state is the element counter.
+    {
+      uint32_t nn = (uint32_t)hi + 1;             // i + 1 of the element being drawn
+      const uint32_t nn_end = (uint32_t)lo;       // stop once nn == lo  (element lo - 1 is not ours)
+      uint32_t cnt = 0;
+      while (nn > nn_end) {
+        const int shift = __builtin_clz(nn);      // 32 - bit_length(nn); constant while nn >= 2^(k-1)
+        const uint32_t band_end = std::max(nn_end, (1u << (31 - shift)) - 1u);  // last nn of this band, exclusive
+        while (nn > band_end) {
+          if (w + 256 >= limit) { r.advance_to(w); r.need(8192); limit = w + 8192 - 256; }
+          // a short unrolled burst; bounds: at most 64 elements / words per burst
+          int burst = 64;
+          while (burst-- > 0 && nn > band_end) {
+            const uint32_t c = r.at(w++) >> shift;
+            const uint32_t acc = c < nn;
+            jb[cnt] = c;
+            cnt += acc;
+            nn -= acc;
+          }
+        }
+      }
+      for (uint32_t q = 0; q < cnt; q++) __builtin_prefetch(&p[jb[q]], 1, 1);
+    }
+    // pass B: the swaps, with their targets already on the way
+    for (int i = hi; i >= lo; i--) {
+      const uint32_t j = jb[hi - i];
+      const uint32_t a = p[i], b = p[j];
+      p[i] = b; p[j] = a;
+      if (a == cs) cpos = j; else if (b == cs) cpos = (uint32_t)i;
+    }
+    r.advance_to(w);
   }
-  for (int q = 0; q < n; q++) e->hrank[p[q]] = (uint32_t)q;
+  memcpy(e->hrank, p, (size_t)n * 4);
+  e->rank_clock_host = cs == 0xFFFFFFFFu ? 0xFFFFFFFFu : cpos;
+}
+
+// persistent worker for the scheduler shuffle (a fresh std::thread per tick costs ~50 us and loses locality)
+void shuffle_worker(E* e) {
+  std::unique_lock<std::mutex> lk(e->sh_mu);
+  for (;;) {
+    e->sh_cv.wait(lk, [e]() { return e->sh_req || e->sh_quit; });
+    if (e->sh_quit) return;
+    const int n = e->sh_n;
+    e->sh_req = false;
+    lk.unlock();
+    double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    shuffle_ranks(e, n);
+    e->shuffle_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+    lk.lock();
+    e->sh_done = true;
+    e->sh_cv.notify_all();
+  }
+}
+void shuffle_start(E* e, int n) {
+  if (!e->sh_thread.joinable()) e->sh_thread = std::thread(shuffle_worker, e);
+  std::lock_guard<std::mutex> lk(e->sh_mu);
+  e->sh_n = n; e->sh_done = false; e->sh_req = true;
+  e->sh_cv.notify_all();
+}
+void shuffle_wait(E* e) {
+  std::unique_lock<std::mutex> lk(e->sh_mu);
+  e->sh_cv.wait(lk, [e]() { return e->sh_done; });
+}
+
+inline double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline void host_prof(E* e, int id, double ms, long long items) {
+  if (!e->prof) return;
+  e->prof_ms[id] += ms; e->prof_launches[id]++; e->prof_items[id] += items;
 }
 
 int tick(E* e) {
@@ -1031,8 +1137,9 @@ int tick(E* e) {
   hipStream_t st = e->stream;
   const int nA = e->n_active, nS = e->n_sched;
   // the scheduler stream is independent of everything the decide phase does: shuffle on a host thread
-  std::thread shuffler([e, nS]() { shuffle_ranks(e, nS); });
-  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{shuffler};
+  shuffle_start(e, nS);
+  struct Joiner { E* e; bool done = false; ~Joiner() { if (!done) shuffle_wait(e); } } joiner{e};
+  const double t_tick0 = now_ms();
 
   // density_map is a function of the occupancy at this point (city_model.py:1853)
   HIPOK(hipMemcpyAsync(d.occ_snap, d.occ, (size_t)e->N, hipMemcpyDeviceToDevice, st));
@@ -1052,21 +1159,61 @@ int tick(E* e) {
       }
       HIPOK(hipStreamSynchronize(st));
       // host scan of the global MT19937 stream in active_vehicle_agents order (A7, A8)
-      HostMT& r = e->rng_global;
+      const double t_scan0 = now_ms();
+      MTPipe& r = e->rng_global;
       int ev_at = -1, ev_coll = 0;
       const uint8_t* F = e->hF;
       uint8_t* R = e->hR;
-      for (; i < nA; i++) {
-        uint8_t f = F[i];
-        if (!f) continue;
-        if (f & F_DRAW_MALF) {
-          if (r.random() < P.malfunction_chance) { ev_at = i; ev_coll = 0; break; }
+      // random() < c  <=>  the 53-bit integer (a << 26 | b) < ceil(c * 2^53)   (exact: power-of-two scaling)
+      auto thr53 = [](double c) -> uint64_t {
+        if (!(c > 0.0)) return 0;
+        if (c >= 1.0) return 1ull << 53;
+        return (uint64_t)std::ceil(std::ldexp(c, 53));
+      };
+      const uint64_t T_malf = thr53(P.malfunction_chance), T_swipe = thr53(P.sideswipe_chance);
+      const uint32_t span = (uint32_t)(P.vehicle_max_speed - P.vehicle_min_speed + 1);
+      const int rshift = __builtin_clz(span);  // getrandbits(span.bit_length())
+      uint64_t w = r.pos();
+      const int CH = 1 << 15;
+      while (i < nA && ev_at < 0) {
+        const int hi = std::min(nA, i + CH);
+        r.need((w - r.pos()) + (uint64_t)(hi - i) * 8 + 64 + 1248);
+        r.need_take((w - r.pos()) + (uint64_t)(hi - i) * 8 + 64);
+        for (; i < hi; i++) {
+          const uint32_t f = F[i];
+          if (f & F_DRAW_MALF) {
+            const uint64_t k = ((uint64_t)(r.at(w) >> 5) << 26) | (uint64_t)(r.at(w + 1) >> 6);
+            w += 2;
+            if (__builtin_expect(k < T_malf, 0)) { ev_at = i; ev_coll = 0; break; }
+          }
+          if (__builtin_expect(f & F_DRAW_SWIPE, 0)) {
+            const uint64_t k = ((uint64_t)(r.at(w) >> 5) << 26) | (uint64_t)(r.at(w + 1) >> 6);
+            w += 2;
+            if (k < T_swipe) { ev_at = i; ev_coll = 1; break; }
+          }
+          // randint(min, max) = min + _randbelow(span): retried while the top bits are >= span.  The number of
+          // words such a draw consumes from position w was tabulated by the producer thread, so the serial chain
+          // through `w` is one byte load per draw.
+          const uint32_t want = (f >> 2) & 1u;
+          uint32_t take = r.take(w);
+          if (__builtin_expect(want && take == 0, 0)) {
+            uint64_t q = w;
+            for (;;) {
+              if (q - r.pos() + 8 > MTPipe::MAX_AHEAD_BLOCKS * 600) { r.advance_to(w); }
+              r.need((q - r.pos()) + 8);
+              uint32_t v = r.at(q++) >> rshift;
+              if (v < span) break;
+            }
+            take = (uint32_t)(q - w);
+          }
+          const uint32_t val = r.at(w + take - 1) >> rshift;
+          R[i] = want ? (uint8_t)(P.vehicle_min_speed + (int)val) : (uint8_t)0;
+          w += want ? take : 0u;
         }
-        if (f & F_DRAW_SWIPE) {
-          if (!(r.random() >= P.sideswipe_chance)) { ev_at = i; ev_coll = 1; break; }
-        }
-        if (f & F_DRAW_SPEED) R[i] = (uint8_t)r.randint(P.vehicle_min_speed, P.vehicle_max_speed);
+        r.advance_to(w);
       }
+      if (ev_at >= 0) r.advance_to(w);
+      host_prof(e, PH_SCAN, now_ms() - t_scan0, nA);
       if (ev_at < 0) break;
       // rare: a malfunction / sideswipe fired.  Apply it and re-derive the draw flags of the suffix.
       e->C.rng_fixups++;
@@ -1087,28 +1234,41 @@ int tick(E* e) {
   }
 
   // ---------------- move (schedule.step) ----------------
-  shuffler.join();
-  const uint32_t rank_clock = e->clock_slot >= 0 ? e->hrank[e->clock_slot] : NO_RANK;
+  const double t_dec1 = now_ms();
+  host_prof(e, PH_DECIDE_WALL, t_dec1 - t_tick0, nA);
+  shuffle_wait(e);
+  joiner.done = true;
+  host_prof(e, PH_SHUFFLE_WAIT, now_ms() - t_dec1, nS);
+  host_prof(e, PH_SHUFFLE, e->shuffle_ms, nS);
+  const double t_move0 = now_ms();
+  const uint32_t rank_clock = e->rank_clock_host;
   const double elapsed0 = e->C.elapsed;
   if (nS > 0) {
-    HIPOK(hipMemcpyAsync(d.rank, e->hrank, (size_t)nS * 4, hipMemcpyHostToDevice, st));
+    HIPOK(hipMemcpyAsync(e->d_perm, e->hrank, (size_t)nS * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_rank_invert, dim3(nblk(nS)), dim3(BLK), 0, st, e->d_perm, d.rank, nS);
     HIPOK(hipMemsetAsync(d.resolved, 0, (size_t)nS, st));
     HIPOK(hipMemsetAsync(&d.cnt->resolved, 0, sizeof(int) * 2, st));  // resolved, deaths
-    int done = 0, chunk = 2;
+    // Round 1 covers every slot; later rounds only the slots that were still blocked (ping-pong lists).
+    int done = 0, round_no = 0, pending_bound = nS;
+    HIPOK(hipMemsetAsync(d.cnt->pend_n, 0, sizeof(int) * 2, st));
     while (done < nS) {
-      for (int rr = 0; rr < chunk; rr++) {
+      const int chunk = round_no == 0 ? 1 : 4;
+      for (int rr = 0; rr < chunk; rr++, round_no++) {
         if ((e->epoch % EPOCHS) == 0) {  // epoch prefix wrapped: stale keys would win again -> clear once
           size_t n = (size_t)e->N;
-          HIPOK(hipMemsetAsync(d.cw_occ, 0xFF, n * 4, st));
-          HIPOK(hipMemsetAsync(d.cr_occ, 0xFF, n * 4, st));
-          HIPOK(hipMemsetAsync(d.cw_stop, 0xFF, n * 4, st));
-          HIPOK(hipMemsetAsync(d.cr_stop, 0xFF, n * 4, st));
+          HIPOK(hipMemsetAsync(d.claims, 0xFF, n * 16, st));
           HIPOK(hipMemsetAsync(d.gclaim_r, 0xFF, (size_t)std::max(d.G, 1) * 4, st));
         }
         const uint32_t prefix = (EPOCHS - 1) - (e->epoch % EPOCHS);
         e->epoch++;
-        LAUNCH(e, PK_MOVE_CLAIM, nS, k_move_claim, dim3(nblk(nS)), dim3(BLK), d, P, nS, prefix);
-        LAUNCH(e, PK_MOVE_RESOLVE, nS, k_move_resolve, dim3(nblk(nS)), dim3(BLK), d, P, nS, prefix, rank_clock, elapsed0);
+        const int in = round_no & 1, out = in ^ 1;   // round r reads list[r & 1] (none in round 0), writes the other
+        const int32_t* in_list = round_no == 0 ? nullptr : e->pend_list[in];
+        const int grid_items = round_no == 0 ? nS : pending_bound;
+        HIPOK(hipMemsetAsync(&d.cnt->pend_n[out], 0, sizeof(int), st));
+        LAUNCH(e, PK_MOVE_CLAIM, grid_items, k_move_claim, dim3(nblk(grid_items)), dim3(BLK), d, P, nS, prefix, in_list,
+               &d.cnt->pend_n[in]);
+        LAUNCH(e, PK_MOVE_RESOLVE, grid_items, k_move_resolve, dim3(nblk(grid_items)), dim3(BLK), d, P, nS, prefix,
+               rank_clock, elapsed0, in_list, &d.cnt->pend_n[in], e->pend_list[out], &d.cnt->pend_n[out]);
         e->C.move_rounds++;
       }
       HIPOK(hipMemcpyAsync(e->hint, &d.cnt->resolved, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
@@ -1116,7 +1276,7 @@ int tick(E* e) {
       int now = e->hint[0];
       if (now == done && now < nS) return fail(e, TS_E_DEVICE, "move phase made no progress (internal error)");
       done = now;
-      chunk = 4;
+      pending_bound = std::max(1, nS - done);
     }
     if (e->hint[3]) return fail(e, e->hint[3], "device-side error: a vehicle sits on its target during decide (start == goal is not supported)");
     e->C.agent_steps += e->n_sched_vehicles;
@@ -1135,6 +1295,7 @@ int tick(E* e) {
       }
     }
   }
+  host_prof(e, PH_MOVE_WALL, now_ms() - t_move0, nS);
   if (e->clock_slot >= 0) e->C.elapsed += P.time_per_step_seconds;
   e->C.step_count++;
   if (e->prof) { HIPOK(hipStreamSynchronize(st)); prof_collect(e); }
@@ -1187,7 +1348,7 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   if (hipStreamCreate(&e->stream) != hipSuccess) return bail(TS_E_DEVICE);
 #define A(ptr, n) if (dalloc(e, &ptr, (size_t)(n)) != hipSuccess) return bail(TS_E_DEVICE);
   A(d.occ, N) A(d.stop, N) A(d.stuck, N) A(d.rain, N) A(d.allowed, N) A(d.is_road, N) A(d.road_type, N) A(d.inter, N)
-  A(d.cell_veh, N) A(d.cw_occ, N) A(d.cr_occ, N) A(d.cw_stop, N) A(d.cr_stop, N) A(d.gclaim_r, 1)
+  A(d.cell_veh, N) A(d.claims, N * 4) A(d.gclaim_r, 1)
   A(d.cnt, 1) A(e->d_total, 1) A(e->d_crc, 256) A(d.occ_snap, N) A(e->d_status, 4)
 #undef A
   hipStream_t st = e->stream;
@@ -1215,6 +1376,7 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   ok &= hipStreamSynchronize(st) == hipSuccess;
   if (!ok) return bail(TS_E_DEVICE);
   e->epoch = 0;
+  e->rng_global.set_roll((uint32_t)std::max(1, params->vehicle_max_speed - params->vehicle_min_speed + 1));
   if (ensure_vehicle_capacity(e, 1024, 1024) != TS_OK) return bail(TS_E_DEVICE);
   if (ensure_pool(e, 1 << 16) != TS_OK) return bail(TS_E_DEVICE);
   *out = e;
@@ -1224,6 +1386,11 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
 int ts_destroy(ts_handle e) {
   if (!e) return TS_OK;
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->sh_thread.joinable()) {
+    { std::lock_guard<std::mutex> lk(e->sh_mu); e->sh_quit = true; }
+    e->sh_cv.notify_all();
+    e->sh_thread.join();
+  }
   for (void* p : e->allocs) (void)hipFree(p);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->hF) (void)hipHostFree(e->hF);
@@ -1339,21 +1506,19 @@ int ts_schedule_add(ts_handle e, int32_t kind, int32_t count) {
 
 int ts_seed(ts_handle e, int32_t stream, const uint32_t* mt, uint32_t index) {
   if (!e || !mt || stream < 0 || stream > 1 || index > 624) return TS_E_INVALID;
-  HostMT& r = stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched;
-  memcpy(r.mt, mt, sizeof(r.mt)); r.idx = index;
-  e->seeded[stream] = true;
+  (stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched).seed(mt, index);
   return TS_OK;
 }
 int ts_seed_int(ts_handle e, int32_t stream, uint64_t seed) {
   if (!e || stream < 0 || stream > 1) return TS_E_INVALID;
   (stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched).seed_u64(seed);
-  e->seeded[stream] = true;
   return TS_OK;
 }
 int ts_rng_state(ts_handle e, int32_t stream, uint32_t* mt_out, uint32_t* index_out) {
   if (!e || stream < 0 || stream > 1 || !mt_out || !index_out) return TS_E_INVALID;
-  HostMT& r = stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched;
-  memcpy(mt_out, r.mt, sizeof(r.mt)); *index_out = r.idx;
+  MTPipe& r = stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched;
+  if (!r.seeded()) return fail(e, TS_E_STATE, "stream not seeded");
+  r.state(mt_out, index_out);
   return TS_OK;
 }
 
@@ -1575,7 +1740,7 @@ int ts_debug_set_occupancy(ts_handle e, const int8_t* src) {
 
 int ts_step(ts_handle e, int32_t n_ticks) {
   if (!e || n_ticks < 0) return TS_E_INVALID;
-  if (!e->seeded[0] || !e->seeded[1]) return fail(e, TS_E_STATE, "both RNG streams must be seeded before step");
+  if (!e->rng_global.seeded() || !e->rng_sched.seeded()) return fail(e, TS_E_STATE, "both RNG streams must be seeded before step");
   if (e->groups_scheduled != e->d.G && e->d.G > 0 && e->groups_scheduled != 0)
     return fail(e, TS_E_STATE, "every light group must be scheduled (or none)");
   for (int t = 0; t < n_ticks; t++) {
