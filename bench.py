@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # gathers 32 + writes 24, split over the kernels that do that work.  k_move_claim is
 # pure parallelisation overhead: 0 algorithmic bytes.
 ALGO_BYTES = {"k_decide_pre": 10, "k_decide_main": 44, "k_move_claim": 0, "k_move_resolve": 26,
-              "k_compact": 0, "k_apply_event": 0}
+              "k_compact": 0, "k_apply_event": 0, "k_rng": 0, "k_decide_replan": 0, "k_density": 0}
 
 # "config 2" policy of BASELINE.md: car-following + movement kernels only.  Lights disabled, replans
 # gated off; malfunction / sideswipe chances 0 (their draws are still consumed) because a stranded

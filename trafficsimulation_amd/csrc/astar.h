@@ -572,6 +572,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
 __global__ void k_decide_main(Dev d, TsParams P, int n_active, int32_t* replan_list) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_active) return;
+  if (d.cnt->rng_event != 0xFFFFFFFFu) return;  // a malfunction / sideswipe fired: the host re-runs this after the fix-up
   if (decide_vehicle(d, P, i, nullptr) == DV_DEFER) replan_list[atomicAdd(&d.cnt->replan_n[0], 1)] = i;
 }
 

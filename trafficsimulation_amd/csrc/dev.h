@@ -19,6 +19,7 @@ constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
 
 // decide-phase flag byte F (k_decide_pre -> host scan)
 constexpr uint8_t F_DRAW_MALF = 1, F_DRAW_SWIPE = 2, F_DRAW_SPEED = 4;
+constexpr uint32_t WORDS_MASK = (1u << 23) - 1;  // = MTPipe::TW_CAP - 1
 
 struct DevCnt {
   long long stuck, collisions, malfunctions, overtaking, in_stuck_detour, parked, live_internal, live_through,
@@ -32,7 +33,9 @@ struct DevCnt {
   unsigned long long pool_used;  // words handed out from the path pool (device-side bump allocator)
   long long astar_calls, astar_exp, astar_relax;
   int pend_n[2];   // lengths of the two ping-pong lists of still-unresolved schedule slots
-  int pad_[2];
+  unsigned int rng_event;   // first (vehicle index * 2 + is_collision) whose draw fired this pass, 0xFFFFFFFF = none
+  unsigned int rng_tot[2];  // pass 1 totals: fixed words, number of speed rolls
+  int pad_;
 };
 
 struct Dev {
@@ -79,6 +82,9 @@ struct Dev {
   // decide-phase exchange buffers
   uint8_t *F, *R;
   int32_t* cand;
+  // decide-phase RNG bookkeeping on the device (see k_rng_* in engine.hip)
+  uint32_t* words;      // ring mirror of the global MT19937 stream (tempered words), index = absolute & WORDS_MASK
+  uint32_t *Cx, *rollrank, *rollD, *Tcum;
   DevCnt* cnt;
 };
 

@@ -663,6 +663,128 @@ __global__ void k_rank_invert(const uint32_t* perm, uint32_t* rank, int n) {
   if (q < n) rank[perm[q]] = (uint32_t)q;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// decide-phase RNG bookkeeping on the device.  Per vehicle the draw byte F says: 2 words for the malfunction
+// draw, 2 for a sideswipe draw, then a rejection-sampled speed roll.  The fixed parts are a prefix sum
+// (pass 1, here); only the rolls form a serial chain (pass 2, host, ~0.45 chain steps per vehicle through the
+// producer's take table); pass 3 (k_rng_apply) turns stream positions into decisions for every vehicle.
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_ITEMS = 4;
+__device__ __forceinline__ uint2 rng_item(uint8_t f) {
+  return make_uint2(2u * (f & 1u) + 2u * ((f >> 1) & 1u), (f >> 2) & 1u);  // (fixed words, is a roller)
+}
+__global__ void k_rng_blocksum(const uint8_t* F, int start, int n, uint2* block_sums) {
+  __shared__ uint2 wsum[BLK / 64];
+  const int base = blockIdx.x * BLK * RS_ITEMS + threadIdx.x * RS_ITEMS;
+  uint2 a = make_uint2(0, 0);
+  for (int j = 0; j < RS_ITEMS; j++) {
+    int i = base + j;
+    if (i < n) { uint2 v = rng_item(F[start + i]); a.x += v.x; a.y += v.y; }
+  }
+  for (int o = 32; o; o >>= 1) { a.x += __shfl_down(a.x, o); a.y += __shfl_down(a.y, o); }
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint2 t = make_uint2(0, 0);
+    for (int w = 0; w < BLK / 64; w++) { t.x += wsum[w].x; t.y += wsum[w].y; }
+    block_sums[blockIdx.x] = t;
+  }
+}
+__global__ void k_rng_scanblocks(uint2* block_sums, int nb, unsigned int* total) {  // single block, exclusive, in place
+  __shared__ uint2 carry;
+  __shared__ uint2 buf[1024];
+  if (threadIdx.x == 0) carry = make_uint2(0, 0);
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    int i = base + threadIdx.x;
+    uint2 v = i < nb ? block_sums[i] : make_uint2(0, 0);
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      uint2 t = threadIdx.x >= o ? buf[threadIdx.x - o] : make_uint2(0, 0);
+      __syncthreads();
+      buf[threadIdx.x].x += t.x; buf[threadIdx.x].y += t.y;
+      __syncthreads();
+    }
+    if (i < nb) block_sums[i] = make_uint2(carry.x + buf[threadIdx.x].x - v.x, carry.y + buf[threadIdx.x].y - v.y);
+    __syncthreads();
+    if (threadIdx.x == 1023) { carry.x += buf[1023].x; carry.y += buf[1023].y; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { total[0] = carry.x; total[1] = carry.y; }
+}
+__global__ void k_rng_final(Dev d, int start, int n, const uint2* block_off) {
+  __shared__ uint2 tsum[BLK];
+  const int base = blockIdx.x * BLK * RS_ITEMS + threadIdx.x * RS_ITEMS;
+  uint2 item[RS_ITEMS];
+  uint2 a = make_uint2(0, 0);
+  for (int j = 0; j < RS_ITEMS; j++) {
+    int i = base + j;
+    item[j] = i < n ? rng_item(d.F[start + i]) : make_uint2(0, 0);
+    a.x += item[j].x; a.y += item[j].y;
+  }
+  tsum[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 1; o < BLK; o <<= 1) {  // inclusive scan of the per-thread sums
+    uint2 t = threadIdx.x >= o ? tsum[threadIdx.x - o] : make_uint2(0, 0);
+    __syncthreads();
+    tsum[threadIdx.x].x += t.x; tsum[threadIdx.x].y += t.y;
+    __syncthreads();
+  }
+  uint2 run = block_off[blockIdx.x];
+  run.x += tsum[threadIdx.x].x - a.x; run.y += tsum[threadIdx.x].y - a.y;
+  for (int j = 0; j < RS_ITEMS; j++) {
+    int i = base + j;
+    if (i >= n) break;
+    d.Cx[start + i] = run.x;          // fixed words consumed by the vehicles before this one (in this pass)
+    d.rollrank[start + i] = run.y;    // rolls before this one
+    if (item[j].y) d.rollD[run.y] = run.x + item[j].x;  // where its roll starts, apart from earlier rolls' lengths
+    run.x += item[j].x; run.y += item[j].y;
+  }
+}
+// take table for the host chain: out[i] = words a speed roll starting at stream position base + i consumes
+// (1 + number of rejected words from there on; 0 = more than 64, the host counts those by hand)
+__global__ void k_rng_take(const uint32_t* words, unsigned long long base, int n, uint32_t span, int rshift, uint8_t* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long p = base + (unsigned long long)i;
+  int t = 1;
+  while (t <= 64 && (words[(p + t - 1) & WORDS_MASK] >> rshift) >= span) t++;
+  out[i] = t <= 64 ? (uint8_t)t : (uint8_t)0;
+}
+
+// pass 3: every vehicle of [start, start + n) reads its words.  base = stream position of vehicle `start`.
+__global__ void k_rng_apply(Dev d, int start, int n, unsigned long long base, unsigned long long t_malf,
+                            unsigned long long t_swipe, uint32_t span, int rshift, int min_speed) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int i = start + t;
+  const uint32_t f = d.F[i];
+  const uint32_t rr = d.rollrank[i];
+  const uint32_t tb = d.Tcum[rr];
+  unsigned long long w = base + d.Cx[i] + tb;
+  uint8_t roll = 0;
+  bool fired = false;
+  if (f & F_DRAW_MALF) {
+    const unsigned long long k = ((unsigned long long)(d.words[w & WORDS_MASK] >> 5) << 26) |
+                                 (unsigned long long)(d.words[(w + 1) & WORDS_MASK] >> 6);
+    w += 2;
+    if (k < t_malf) { atomicMin(&d.cnt->rng_event, (unsigned int)i * 2u); fired = true; }
+  }
+  if (!fired && (f & F_DRAW_SWIPE)) {
+    const unsigned long long k = ((unsigned long long)(d.words[w & WORDS_MASK] >> 5) << 26) |
+                                 (unsigned long long)(d.words[(w + 1) & WORDS_MASK] >> 6);
+    w += 2;
+    if (k < t_swipe) { atomicMin(&d.cnt->rng_event, (unsigned int)i * 2u + 1u); fired = true; }
+  } else if (f & F_DRAW_SWIPE) w += 2;
+  if (!fired && (f & F_DRAW_SPEED)) {
+    const uint32_t tk = d.Tcum[rr + 1] - tb;
+    roll = (uint8_t)(min_speed + (int)(d.words[(w + tk - 1) & WORDS_MASK] >> rshift));
+  }
+  d.R[i] = roll;
+}
+
 template <typename T>
 __global__ void k_fill(T* p, T v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -716,6 +838,18 @@ struct ts_engine {
   TsCounters C;
   std::vector<uint32_t> perm, shuffle_j;
   int32_t* pend_list[2] = {nullptr, nullptr};
+  // device-side RNG bookkeeping
+  uint32_t* h_words = nullptr;        // pinned storage of the global stream's tempered-word ring
+  uint64_t words_uploaded = 0;        // absolute word index up to which d.words mirrors it
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t words_ev = nullptr;
+  uint2* rng_blocks = nullptr;
+  int cap_rng_blocks = 0;
+  uint32_t *h_rollD = nullptr, *h_Tcum = nullptr;
+  int roll_guess = 0;
+  uint8_t *d_take = nullptr, *h_take = nullptr;   // take table of the stream range the next pass will walk
+  size_t cap_take = 0;
+  uint64_t take_guess = 0;
   std::thread sh_thread;
   std::mutex sh_mu;
   std::condition_variable sh_cv;
@@ -738,8 +872,8 @@ struct ts_engine {
   struct ProfRec { int id; int e0, e1; long long items; };
   std::vector<ProfRec> prof_pending;
   size_t ev_used = 0;
-  double prof_ms[16] = {0};
-  long long prof_launches[16] = {0}, prof_items[16] = {0};
+  double prof_ms[24] = {0};
+  long long prof_launches[24] = {0}, prof_items[24] = {0};
   double shuffle_ms = 0;
 };
 
@@ -747,10 +881,11 @@ namespace {
 
 typedef ts_engine E;
 
-enum { PK_DECIDE_PRE = 0, PK_DECIDE_MAIN, PK_MOVE_CLAIM, PK_MOVE_RESOLVE, PK_COMPACT, PK_EVENT, PK_REPLAN, PK_DENSITY, PH_SCAN, PH_SHUFFLE, PH_SHUFFLE_WAIT, PH_DECIDE_WALL, PH_MOVE_WALL, PK_COUNT };
+enum { PK_DECIDE_PRE = 0, PK_DECIDE_MAIN, PK_MOVE_CLAIM, PK_MOVE_RESOLVE, PK_COMPACT, PK_EVENT, PK_REPLAN, PK_DENSITY, PK_RNG, PH_SCAN, PH_SHUFFLE, PH_SHUFFLE_WAIT, PH_DECIDE_WALL, PH_MOVE_WALL, PH_WAIT1, PH_WORDS, PH_WAIT3, PH_NEED, PK_COUNT };
 const char* PK_NAMES[PK_COUNT] = {"k_decide_pre", "k_decide_main", "k_move_claim", "k_move_resolve",
-                                  "k_compact", "k_apply_event", "k_decide_replan", "k_density",
-                                  "host_rng_scan", "host_shuffle", "host_shuffle_wait", "host_decide_wall", "host_move_wall"};
+                                  "k_compact", "k_apply_event", "k_decide_replan", "k_density", "k_rng",
+                                  "host_rng_scan", "host_shuffle", "host_shuffle_wait", "host_decide_wall", "host_move_wall",
+                                  "host_wait_pass1", "host_words_upload", "host_wait_pass3", "host_words_need"};
 
 int prof_begin(E* e, int id, long long items) {
   if (!e->prof) return -1;
@@ -836,6 +971,19 @@ int ensure_vehicle_capacity(E* e, int need_v, int need_sched) {
     { int rc = regrow(e, &d.F, 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &d.R, 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &d.cand, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &d.Cx, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &d.rollrank, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &d.rollD, 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &d.Tcum, 0, (size_t)nc + 1); if (rc) return rc; }
+    {
+      int nbk = nblk(nc, BLK * RS_ITEMS) + 1;
+      int rc = regrow(e, &e->rng_blocks, 0, (size_t)nbk); if (rc) return rc;
+      e->cap_rng_blocks = nbk;
+    }
+    if (e->h_rollD) (void)hipHostFree(e->h_rollD);
+    if (e->h_Tcum) (void)hipHostFree(e->h_Tcum);
+    HIPOK(hipHostMalloc((void**)&e->h_rollD, (size_t)nc * 4));
+    HIPOK(hipHostMalloc((void**)&e->h_Tcum, ((size_t)nc + 1) * 4));
     e->cap_v = nc;
   }
   if (need_sched > e->cap_sched) {
@@ -1123,6 +1271,28 @@ void shuffle_wait(E* e) {
   e->sh_cv.wait(lk, [e]() { return e->sh_done; });
 }
 
+// mirror the global stream's tempered words [uploaded, upto) into the device ring (copy stream + event)
+int words_upload(E* e, uint64_t upto) {
+  MTPipe& r = e->rng_global;
+  if (e->words_uploaded < r.pos()) e->words_uploaded = r.pos();
+  if (upto <= e->words_uploaded) return TS_OK;
+  if (upto - r.pos() > MTPipe::MAX_AHEAD_BLOCKS * 600ull)
+    return fail(e, TS_E_CAPACITY, "one decide pass would read more of the MT19937 stream than the ring holds");
+  { const double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    r.need(upto - r.pos());
+    if (e->prof) { e->prof_ms[PH_WAIT1 + 3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; e->prof_launches[PH_WAIT1 + 3]++; } }
+  uint64_t a = e->words_uploaded;
+  while (a < upto) {
+    const uint64_t off = a & (MTPipe::TW_CAP - 1);
+    const uint64_t len = std::min<uint64_t>(upto - a, MTPipe::TW_CAP - off);
+    HIPOK(hipMemcpyAsync(e->d.words + off, e->h_words + off, len * 4, hipMemcpyHostToDevice, e->copy_stream));
+    a += len;
+  }
+  HIPOK(hipEventRecord(e->words_ev, e->copy_stream));
+  e->words_uploaded = upto;
+  return TS_OK;
+}
+
 inline double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -1148,88 +1318,147 @@ int tick(E* e) {
   if (nA > 0) {
     HIPOK(hipMemsetAsync(d.ev, 0, (size_t)e->n_vehicles_total, st));
     HIPOK(hipMemsetAsync(d.cnt->replan_n, 0, sizeof(int) * 6, st));
+    // random() < c  <=>  the 53-bit integer (a << 26 | b) < ceil(c * 2^53)   (exact: power-of-two scaling)
+    auto thr53 = [](double c) -> unsigned long long {
+      if (!(c > 0.0)) return 0;
+      if (c >= 1.0) return 1ull << 53;
+      return (unsigned long long)std::ceil(std::ldexp(c, 53));
+    };
+    const unsigned long long T_malf = thr53(P.malfunction_chance), T_swipe = thr53(P.sideswipe_chance);
+    const uint32_t span = (uint32_t)(P.vehicle_max_speed - P.vehicle_min_speed + 1);
+    const int rshift = __builtin_clz(span);  // getrandbits(span.bit_length())
+    MTPipe& r = e->rng_global;
+    const int SEG = 1 << 20;  // vehicles per pass (bounds the look-ahead into the word ring)
     int start = 0;
-    int i = 0;
-    memset(e->hR, 0, nA);
-    while (true) {
-      int cnt = nA - start;
-      if (cnt > 0) {
-        LAUNCH(e, PK_DECIDE_PRE, cnt, k_decide_pre, dim3(nblk(cnt)), dim3(BLK), d, P, start, nA);
-        HIPOK(hipMemcpyAsync(e->hF + start, d.F + start, cnt, hipMemcpyDeviceToHost, st));
+    bool main_done = false;
+    LAUNCH(e, PK_DECIDE_PRE, nA, k_decide_pre, dim3(nblk(nA)), dim3(BLK), d, P, 0, nA);
+    while (start < nA) {
+      const int seg_end = std::min(nA, start + SEG), n = seg_end - start;
+      const int nb = nblk(n, BLK * RS_ITEMS);
+      // pass 1 (device): fixed-word prefix sums, roll ranks, roll start offsets
+      HIPOK(hipMemsetAsync(&d.cnt->rng_event, 0xFF, sizeof(unsigned int), st));
+      {
+        int tok = prof_begin(e, PK_RNG, n);
+        hipLaunchKernelGGL(k_rng_blocksum, dim3(nb), dim3(BLK), 0, st, d.F, start, n, e->rng_blocks);
+        hipLaunchKernelGGL(k_rng_scanblocks, dim3(1), dim3(1024), 0, st, e->rng_blocks, nb, d.cnt->rng_tot);
+        hipLaunchKernelGGL(k_rng_final, dim3(nb), dim3(BLK), 0, st, d, start, n, e->rng_blocks);
+        prof_end(e, tok);
       }
+      // take table for the stretch of the stream this pass will most likely walk (estimate from the last pass;
+      // positions beyond it fall back to the accept bitmask on the host)
+      const uint64_t base = r.pos();
+      size_t n_take = (size_t)std::min<uint64_t>(e->cap_take, e->take_guess);
+      if (n_take > 0) {
+        if (e->words_uploaded < base + n_take + 64) n_take = e->words_uploaded > base + 64 ? (size_t)(e->words_uploaded - base - 64) : 0;
+      }
+      if (n_take > 0) {
+        HIPOK(hipStreamWaitEvent(st, e->words_ev, 0));
+        hipLaunchKernelGGL(k_rng_take, dim3(nblk((long long)n_take)), dim3(BLK), 0, st, d.words, (unsigned long long)base,
+                           (int)n_take, span, rshift, e->d_take);
+        HIPOK(hipMemcpyAsync(e->h_take, e->d_take, n_take, hipMemcpyDeviceToHost, st));
+      }
+      const int guess = std::min(n, e->roll_guess);
+      HIPOK(hipMemcpyAsync(e->hint + 4, d.cnt->rng_tot, sizeof(unsigned int) * 2, hipMemcpyDeviceToHost, st));
+      if (guess > 0) HIPOK(hipMemcpyAsync(e->h_rollD, d.rollD, (size_t)guess * 4, hipMemcpyDeviceToHost, st));
+      const double t_w1 = now_ms();
       HIPOK(hipStreamSynchronize(st));
-      // host scan of the global MT19937 stream in active_vehicle_agents order (A7, A8)
+      host_prof(e, PH_WAIT1, now_ms() - t_w1, n);
+      const uint32_t Ctot = (uint32_t)e->hint[4];
+      const int cnt = e->hint[5];
+      if (cnt > guess) {
+        HIPOK(hipMemcpyAsync(e->h_rollD + guess, d.rollD + guess, (size_t)(cnt - guess) * 4, hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+      }
+      e->roll_guess = cnt + cnt / 8 + 1024;
+      // pass 2 (host): the serial chain over the speed rolls.  Roll k starts at base + rollD[k] + (words taken by
+      // the rolls before it); the producer thread tabulated how many words a roll takes from any position.
       const double t_scan0 = now_ms();
-      MTPipe& r = e->rng_global;
-      int ev_at = -1, ev_coll = 0;
-      const uint8_t* F = e->hF;
-      uint8_t* R = e->hR;
-      // random() < c  <=>  the 53-bit integer (a << 26 | b) < ceil(c * 2^53)   (exact: power-of-two scaling)
-      auto thr53 = [](double c) -> uint64_t {
-        if (!(c > 0.0)) return 0;
-        if (c >= 1.0) return 1ull << 53;
-        return (uint64_t)std::ceil(std::ldexp(c, 53));
-      };
-      const uint64_t T_malf = thr53(P.malfunction_chance), T_swipe = thr53(P.sideswipe_chance);
-      const uint32_t span = (uint32_t)(P.vehicle_max_speed - P.vehicle_min_speed + 1);
-      const int rshift = __builtin_clz(span);  // getrandbits(span.bit_length())
-      uint64_t w = r.pos();
-      const int CH = 1 << 15;
-      while (i < nA && ev_at < 0) {
-        const int hi = std::min(nA, i + CH);
-        r.need((w - r.pos()) + (uint64_t)(hi - i) * 8 + 64 + 1248);
-        r.need_take((w - r.pos()) + (uint64_t)(hi - i) * 8 + 64);
-        for (; i < hi; i++) {
-          const uint32_t f = F[i];
-          if (f & F_DRAW_MALF) {
-            const uint64_t k = ((uint64_t)(r.at(w) >> 5) << 26) | (uint64_t)(r.at(w + 1) >> 6);
-            w += 2;
-            if (__builtin_expect(k < T_malf, 0)) { ev_at = i; ev_coll = 0; break; }
+      uint32_t* Tcum = e->h_Tcum;
+      const uint8_t* take_tab = e->h_take;
+      const uint32_t* rollD = e->h_rollD;
+      Tcum[0] = 0;
+      {
+        uint64_t T = 0, ensured = 0;
+        for (int k = 0; k < cnt; k++) {
+          const uint64_t pos = base + rollD[k] + T;
+          if (__builtin_expect(pos + 8 >= ensured, 0)) {
+            const uint64_t want = (pos - r.pos()) + (1u << 18);
+            r.need(want + 1248);
+            ensured = pos + (1u << 18) - 64;
           }
-          if (__builtin_expect(f & F_DRAW_SWIPE, 0)) {
-            const uint64_t k = ((uint64_t)(r.at(w) >> 5) << 26) | (uint64_t)(r.at(w + 1) >> 6);
-            w += 2;
-            if (k < T_swipe) { ev_at = i; ev_coll = 1; break; }
-          }
-          // randint(min, max) = min + _randbelow(span): retried while the top bits are >= span.  The number of
-          // words such a draw consumes from position w was tabulated by the producer thread, so the serial chain
-          // through `w` is one byte load per draw.
-          const uint32_t want = (f >> 2) & 1u;
-          uint32_t take = r.take(w);
-          if (__builtin_expect(want && take == 0, 0)) {
-            uint64_t q = w;
+          const uint64_t rel = pos - base;
+          uint32_t t = rel < n_take ? take_tab[rel] : r.take(pos);
+          if (__builtin_expect(t == 0, 0)) {  // run longer than the table records: count it here
+            uint64_t q = pos;
             for (;;) {
-              if (q - r.pos() + 8 > MTPipe::MAX_AHEAD_BLOCKS * 600) { r.advance_to(w); }
               r.need((q - r.pos()) + 8);
-              uint32_t v = r.at(q++) >> rshift;
-              if (v < span) break;
+              if ((r.at(q++) >> rshift) < span) break;
             }
-            take = (uint32_t)(q - w);
+            t = (uint32_t)(q - pos);
           }
-          const uint32_t val = r.at(w + take - 1) >> rshift;
-          R[i] = want ? (uint8_t)(P.vehicle_min_speed + (int)val) : (uint8_t)0;
-          w += want ? take : 0u;
+          T += t;
+          Tcum[k + 1] = (uint32_t)T;
         }
-        r.advance_to(w);
+        host_prof(e, PH_SCAN, now_ms() - t_scan0, n);
+        const uint64_t final_pos = base + Ctot + T;
+        e->take_guess = (Ctot + T) + (Ctot + T) / 8 + (1u << 16);
+        // the words this pass reads must be on the device (usually prefetched during the previous tick)
+        const double t_wu = now_ms();
+        int rc = words_upload(e, final_pos + 8);
+        if (rc) return rc;
+        host_prof(e, PH_WORDS, now_ms() - t_wu, n);
+        HIPOK(hipStreamWaitEvent(st, e->words_ev, 0));
+        HIPOK(hipMemcpyAsync(d.Tcum, Tcum, ((size_t)cnt + 1) * 4, hipMemcpyHostToDevice, st));
+        // pass 3 (device): every vehicle reads its words: malfunction / sideswipe tests, rolled speeds
+        {
+          int tok = prof_begin(e, PK_RNG, n);
+          hipLaunchKernelGGL(k_rng_apply, dim3(nblk(n)), dim3(BLK), 0, st, d, start, n, (unsigned long long)base, T_malf,
+                             T_swipe, span, rshift, P.vehicle_min_speed);
+          prof_end(e, tok);
+        }
+        if (seg_end == nA) {  // k_decide_main returns at once if a draw fired (the fix-up below re-runs it)
+          LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, e->replan_list[0]);
+          HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+        }
+        HIPOK(hipMemcpyAsync(e->hint + 6, &d.cnt->rng_event, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        const double t_w3 = now_ms();
+        HIPOK(hipStreamSynchronize(st));
+        host_prof(e, PH_WAIT3, now_ms() - t_w3, n);
+        const unsigned int evk = (unsigned int)e->hint[6];
+        if (evk == 0xFFFFFFFFu) {
+          r.advance_to(final_pos);
+          start = seg_end;
+          main_done = seg_end == nA;
+          continue;
+        }
+        // rare: a malfunction / sideswipe fired at vehicle ev_at.  Everything before it stands; apply the event,
+        // move the stream to just behind its draws and re-derive the draw bytes of the suffix.
+        e->C.rng_fixups++;
+        const int ev_at = (int)(evk >> 1), ev_coll = (int)(evk & 1u);
+        uint32_t cx = 0, rr = 0;
+        uint8_t fbyte = 0;
+        HIPOK(hipMemcpyAsync(&e->hint[0], d.active + ev_at, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPOK(hipMemcpyAsync(&e->hint[1], d.cand + ev_at, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPOK(hipMemcpyAsync(&cx, d.Cx + ev_at, 4, hipMemcpyDeviceToHost, st));
+        HIPOK(hipMemcpyAsync(&rr, d.rollrank + ev_at, 4, hipMemcpyDeviceToHost, st));
+        HIPOK(hipMemcpyAsync(&fbyte, d.F + ev_at, 1, hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        const uint64_t after = base + cx + Tcum[rr] + (ev_coll ? ((fbyte & F_DRAW_MALF) ? 4u : 2u) : 2u);
+        r.advance_to(after);
+        LAUNCH(e, PK_EVENT, 1, k_apply_event, dim3(1), dim3(64), d, P, e->hint[0], ev_coll, e->hint[1], ev_at);
+        start = ev_at + 1;
+        if (start < nA) LAUNCH(e, PK_DECIDE_PRE, nA - start, k_decide_pre, dim3(nblk(nA - start)), dim3(BLK), d, P, start, nA);
       }
-      if (ev_at >= 0) r.advance_to(w);
-      host_prof(e, PH_SCAN, now_ms() - t_scan0, nA);
-      if (ev_at < 0) break;
-      // rare: a malfunction / sideswipe fired.  Apply it and re-derive the draw flags of the suffix.
-      e->C.rng_fixups++;
-      int ids[2];
-      HIPOK(hipMemcpyAsync(&e->hint[0], d.active + ev_at, sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPOK(hipMemcpyAsync(&e->hint[1], d.cand + ev_at, sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPOK(hipStreamSynchronize(st));
-      ids[0] = e->hint[0]; ids[1] = e->hint[1];
-      LAUNCH(e, PK_EVENT, 1, k_apply_event, dim3(1), dim3(64), d, P, ids[0], ev_coll, ids[1], ev_at);
-      i = ev_at + 1;
-      start = i;
     }
-    HIPOK(hipMemcpyAsync(d.R, e->hR, nA, hipMemcpyHostToDevice, st));
-    LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, e->replan_list[0]);
-    HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
-    HIPOK(hipStreamSynchronize(st));
+    if (!main_done) {  // the last pass ended with an event at the very last vehicle (or there was no pass left)
+      HIPOK(hipMemsetAsync(&d.cnt->rng_event, 0xFF, sizeof(unsigned int), st));
+      LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, e->replan_list[0]);
+      HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+      HIPOK(hipStreamSynchronize(st));
+    }
+    // prefetch the part of the stream the next tick will most likely read
+    { const double t_wu = now_ms(); int rc = words_upload(e, r.pos() + (uint64_t)nA * 4 + (1u << 16)); if (rc) return rc;
+      host_prof(e, PH_WORDS, now_ms() - t_wu, nA); }
     if (e->hint[8] > 0) { int rc = run_replans(e, e->hint[8]); if (rc) return rc; }
   }
 
@@ -1375,6 +1604,15 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   ok &= hipHostMalloc((void**)&e->hint, sizeof(int) * 16) == hipSuccess;
   ok &= hipStreamSynchronize(st) == hipSuccess;
   if (!ok) return bail(TS_E_DEVICE);
+  ok = hipHostMalloc((void**)&e->h_words, MTPipe::TW_CAP * 4) == hipSuccess;
+  ok &= dalloc(e, &d.words, (size_t)MTPipe::TW_CAP) == hipSuccess;
+  ok &= hipStreamCreate(&e->copy_stream) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&e->words_ev, hipEventDisableTiming) == hipSuccess;
+  if (!ok) return bail(TS_E_DEVICE);
+  e->rng_global.use_storage(e->h_words);
+  e->cap_take = 6u << 20;
+  if (dalloc(e, &e->d_take, e->cap_take) != hipSuccess) return bail(TS_E_DEVICE);
+  if (hipHostMalloc((void**)&e->h_take, e->cap_take) != hipSuccess) return bail(TS_E_DEVICE);
   e->epoch = 0;
   e->rng_global.set_roll((uint32_t)std::max(1, params->vehicle_max_speed - params->vehicle_min_speed + 1));
   if (ensure_vehicle_capacity(e, 1024, 1024) != TS_OK) return bail(TS_E_DEVICE);
@@ -1397,9 +1635,16 @@ int ts_destroy(ts_handle e) {
   if (e->hR) (void)hipHostFree(e->hR);
   if (e->hrank) (void)hipHostFree(e->hrank);
   if (e->hcnt) (void)hipHostFree(e->hcnt);
+  if (e->h_rollD) (void)hipHostFree(e->h_rollD);
+  if (e->h_Tcum) (void)hipHostFree(e->h_Tcum);
+  if (e->h_take) (void)hipHostFree(e->h_take);
+  if (e->words_ev) (void)hipEventDestroy(e->words_ev);
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->hint) (void)hipHostFree(e->hint);
   if (e->stream) (void)hipStreamDestroy(e->stream);
-  delete e;
+  uint32_t* hw = e->h_words;
+  delete e;                       // stops the producer threads before their ring storage goes away
+  if (hw) (void)hipHostFree(hw);
   return TS_OK;
 }
 
@@ -1507,11 +1752,13 @@ int ts_schedule_add(ts_handle e, int32_t kind, int32_t count) {
 int ts_seed(ts_handle e, int32_t stream, const uint32_t* mt, uint32_t index) {
   if (!e || !mt || stream < 0 || stream > 1 || index > 624) return TS_E_INVALID;
   (stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched).seed(mt, index);
+  if (stream == TS_RNG_GLOBAL) e->words_uploaded = e->rng_global.pos();
   return TS_OK;
 }
 int ts_seed_int(ts_handle e, int32_t stream, uint64_t seed) {
   if (!e || stream < 0 || stream > 1) return TS_E_INVALID;
   (stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched).seed_u64(seed);
+  if (stream == TS_RNG_GLOBAL) e->words_uploaded = e->rng_global.pos();
   return TS_OK;
 }
 int ts_rng_state(ts_handle e, int32_t stream, uint32_t* mt_out, uint32_t* index_out) {
