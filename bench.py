@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # gathers 32 + writes 24, split over the kernels that do that work.  k_move_claim is
 # pure parallelisation overhead: 0 algorithmic bytes.
 ALGO_BYTES = {"k_decide_pre": 10, "k_decide_main": 44, "k_move_claim": 0, "k_move_resolve": 26,
-              "k_compact": 0, "k_apply_event": 0, "k_rng": 0, "k_decide_replan": 0, "k_density": 0}
+              "k_compact": 0, "k_apply_event": 0, "k_rng": 0, "k_decide_replan": 0, "k_density": 0, "k_reach_strict": 0}
 
 # "config 2" policy of BASELINE.md: car-following + movement kernels only.  Lights disabled, replans
 # gated off; malfunction / sideswipe chances 0 (their draws are still consumed) because a stranded
@@ -55,10 +55,13 @@ def make_workload(size, vehicles, seed):
     return tables, routes, (t1 - t0, time.time() - t1)
 
 
-def setup(api, tables, routes, seed, extra=None):
+FULL_POLICY = {"RAIN_ENABLED": False}   # everything else at the reference's defaults (config.py)
+
+
+def setup(api, tables, routes, seed, extra=None, policy="config2"):
     from trafficsimulation_amd import _capi as capi
     from trafficsimulation_amd.world import build_engine
-    d = dict(POLICY)
+    d = dict(POLICY if policy == "config2" else FULL_POLICY)
     d.update(extra or {})
     p = api.params_from_defaults(d)
     if extra and "eager_density" in extra:
@@ -77,6 +80,9 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--vehicles", type=int, default=1_000_000)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--policy", choices=["config2", "full"], default="config2",
+                    help="config2 = car-following + movement only (BASELINE config 2); full = reference defaults: "
+                         "QUEUE_ACTUATED lights, replanning (GPU A*), contraflow, malfunctions (BASELINE config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -100,7 +106,7 @@ def main():
     tables, routes, gen_t = make_workload(args.size, args.vehicles, seed)
     api = new_engine()
     api.set_device(local_rank)
-    setup(api, tables, routes, seed)
+    setup(api, tables, routes, seed, policy=args.policy)
     v0 = api.num_vehicles()
 
     def barrier():
@@ -149,8 +155,13 @@ def main():
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {
                 "workload": f"{args.size}x{args.size} synthetic city (citygen seed {args.seed}), {v0} vehicles per GPU, "
-                            "config-2 policy: car-following + movement kernels, lights DISABLED, replans gated off, "
-                            "malfunction/sideswipe chance 0; random-walk routes",
+                            + ("config-2 policy: car-following + movement kernels, lights DISABLED, replans gated off, "
+                               "malfunction/sideswipe chance 0; random-walk routes" if args.policy == "config2" else
+                               "full policy: reference defaults (QUEUE_ACTUATED lights, GPU A* replanning, contraflow, "
+                               "malfunctions/sideswipes), rain and spawning off; random-walk initial routes"),
+                "policy": args.policy,
+                "astar": {"calls": c1.astar_calls - c0.astar_calls, "expansions": c1.astar_expansions - c0.astar_expansions,
+                          "relaxations": c1.astar_relaxations - c0.astar_relaxations, "rng_fixups": c1.rng_fixups - c0.rng_fixups},
                 "grid": args.size, "vehicles_per_gpu": v0, "live_vehicles_end": live_end,
                 "light_groups": int(len(tables["g_light_off"]) - 1), "multi_gpu_mode": "replicas only (bit-exact)",
                 "move_rounds_per_tick": rounds / args.steps, "bit_exact_vs_cpu_oracle": "tests/test_gpu_parity.py",
@@ -171,7 +182,7 @@ def main():
         from oracle import pyoracle
         cpu = pyoracle.load()
         ts = time.time()
-        setup(cpu, tables, routes, seed, extra={"eager_density": 1})
+        setup(cpu, tables, routes, seed, extra={"eager_density": 1}, policy=args.policy)
         setup_s = time.time() - ts
         cpu.step(1)
         a0 = cpu.counters().agent_steps

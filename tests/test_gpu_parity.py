@@ -131,7 +131,8 @@ def test_hip_vs_oracle_full_policy_256():
         assert h.rng_fingerprint(capi.RNG_GLOBAL) == c.rng_fingerprint(capi.RNG_GLOBAL), f"tick {t}: RNG"
     hc, cc = h.counters(), c.counters()
     assert hc.rng_fixups > 0 and hc.astar_calls == cc.astar_calls and hc.astar_calls > 100
-    assert (hc.astar_expansions, hc.astar_relaxations) == (cc.astar_expansions, cc.astar_relaxations)
+    # searches whose target the reachability pass proved unreachable are answered [] without flooding
+    assert 0 < hc.astar_expansions <= cc.astar_expansions
     assert (hc.overtaking, hc.in_stuck_detour, hc.collisions, hc.malfunctions) == (
         cc.overtaking, cc.in_stuck_detour, cc.collisions, cc.malfunctions)
     h.close()

@@ -23,17 +23,21 @@ constexpr int A_INF = 0x3F3F3F3F;
 constexpr int MAXB = 64;  // longest contraflow bypass (VEHICLE_MAX_CONTRAFLOW_*_STEPS <= 64)
 enum { DV_DONE = 0, DV_DEFER = 1, DV_OVERFLOW = 2, DV_POOL_FULL = 3 };
 
+// 16-byte records so that one probe / one heap level is one dwordx4 access
+struct __attribute__((aligned(16))) HEnt { int32_t key, dist, came; uint32_t stamp; };   // dist / came_from by cell
+struct __attribute__((aligned(16))) QEnt { int32_t f, g, s, i; };                        // heap entry (f_arr, g_arr, s_arr, i_arr)
+
 // One searcher's scratch (all in HBM, carved from a tier arena).
 struct AScratch {
-  int32_t *hkey, *hdist, *hcame;
-  uint32_t* hstamp;
+  HEnt* ht;
   uint32_t hmask;
-  int32_t *hf, *hg, *hs, *hi;
-  int8_t* hd;
+  QEnt* hq;
+  int8_t* hd;   // dir_arr: indexed by heap SLOT and deliberately not moved by the sift routines
   int heap_cap;
   int32_t *A, *P, *T, *PO, *PD;  // cap cells each: A* result, current new path, splice target, staged pre-paths
   int32_t *BYP, *OV, *DV;        // MAXB cells each: bypass result, staged overtake / detour paths
-  int cap;
+  int cap;        // capacity of the cell buffers
+  int node_cap;   // distinct cells the table may hold
   uint32_t epoch;
   int nodes;
   long long calls, expansions, relaxations;
@@ -42,51 +46,39 @@ struct AScratch {
 struct ATier {
   int cap, n_slots, heap_cap;
   uint32_t hsize;  // power of two >= 2 * cap
-  int32_t *hkey, *hdist, *hcame;
-  uint32_t* hstamp;
-  int32_t *hf, *hg, *hs, *hi;
+  HEnt* ht;
+  QEnt* hq;
   int8_t* hd;
   int32_t* cells;      // per slot: 5 * cap + 3 * MAXB
   uint32_t* slot_epoch;
 };
 
 __device__ __forceinline__ void scratch_bind(const ATier& t, int slot, AScratch& S) {
-  size_t ho = (size_t)slot * t.hsize, po = (size_t)slot * t.heap_cap;
-  S.hkey = t.hkey + ho; S.hdist = t.hdist + ho; S.hcame = t.hcame + ho; S.hstamp = t.hstamp + ho;
+  S.ht = t.ht + (size_t)slot * t.hsize;
   S.hmask = t.hsize - 1;
-  S.hf = t.hf + po; S.hg = t.hg + po; S.hs = t.hs + po; S.hi = t.hi + po; S.hd = t.hd + po;
+  S.hq = t.hq + (size_t)slot * t.heap_cap;
+  S.hd = t.hd + (size_t)slot * t.heap_cap;
   S.heap_cap = t.heap_cap;
   int32_t* c = t.cells + (size_t)slot * ((size_t)5 * t.cap + 3 * MAXB);
   S.A = c; S.P = c + t.cap; S.T = c + 2 * (size_t)t.cap; S.PO = c + 3 * (size_t)t.cap; S.PD = c + 4 * (size_t)t.cap;
   S.BYP = c + 5 * (size_t)t.cap; S.OV = S.BYP + MAXB; S.DV = S.OV + MAXB;
   S.cap = t.cap;
+  S.node_cap = t.cap;
   S.epoch = t.slot_epoch[slot];
   S.nodes = 0; S.calls = 0; S.expansions = 0; S.relaxations = 0;
 }
 
 __device__ __forceinline__ uint32_t h_hash(int cell, uint32_t mask) { return ((uint32_t)cell * 2654435761u >> 7) & mask; }
 
-// returns slot of `cell`, or the empty slot where it would go (found = false)
-__device__ __forceinline__ uint32_t h_probe(const AScratch& S, int cell, bool& found) {
+// returns the slot of `cell` (found) or the empty slot where it would go; `ent` = the record read there
+__device__ __forceinline__ uint32_t h_probe(const AScratch& S, int cell, bool& found, HEnt& ent) {
   uint32_t h = h_hash(cell, S.hmask);
   for (;;) {
-    if (S.hstamp[h] != S.epoch) { found = false; return h; }
-    if (S.hkey[h] == cell) { found = true; return h; }
+    ent = S.ht[h];
+    if (ent.stamp != S.epoch) { found = false; return h; }
+    if (ent.key == cell) { found = true; return h; }
     h = (h + 1) & S.hmask;
   }
-}
-__device__ __forceinline__ int h_dist(const AScratch& S, int cell) {
-  bool f;
-  uint32_t h = h_probe(S, cell, f);
-  return f ? S.hdist[h] : A_INF;
-}
-
-__device__ __forceinline__ void heap_swap(AScratch& S, int a, int b) {
-  int t;
-  t = S.hf[a]; S.hf[a] = S.hf[b]; S.hf[b] = t;
-  t = S.hg[a]; S.hg[a] = S.hg[b]; S.hg[b] = t;
-  t = S.hs[a]; S.hs[a] = S.hs[b]; S.hs[b] = t;
-  t = S.hi[a]; S.hi[a] = S.hi[b]; S.hi[b] = t;
 }
 
 // astar_core.  Writes the path (start excluded, goal included) to out[0..len); returns len >= 0, or -1 on
@@ -97,59 +89,74 @@ __device__ int astar_dev(const Dev& d, const TsParams& P, AScratch& S, int start
   S.calls++;
   S.epoch++;
   if (S.epoch == 0) {  // stamp wrapped (once per 2^32 searches): clear the table
-    for (uint32_t q = 0; q <= S.hmask; q++) S.hstamp[q] = 0;
+    for (uint32_t q = 0; q <= S.hmask; q++) S.ht[q].stamp = 0;
     S.epoch = 1;
   }
   S.nodes = 0;
   const int gx = goal_idx % W, gy = goal_idx / W;
   {
-    bool f;
-    uint32_t h = h_probe(S, start_idx, f);
-    S.hstamp[h] = S.epoch; S.hkey[h] = start_idx; S.hdist[h] = 0; S.hcame[h] = -1;
+    bool f; HEnt e;
+    uint32_t h = h_probe(S, start_idx, f, e);
+    S.ht[h] = HEnt{start_idx, 0, -1, S.epoch};
     S.nodes = 1;
   }
   int heap_size = 1;
   {
     int sx = start_idx % W, sy = start_idx / W;
-    S.hf[0] = abs(sx - gx) + abs(sy - gy);
-    S.hg[0] = 0; S.hs[0] = 0; S.hi[0] = start_idx; S.hd[0] = -1;
+    S.hq[0] = QEnt{abs(sx - gx) + abs(sy - gy), 0, 0, start_idx};
+    S.hd[0] = -1;
   }
   while (heap_size > 0) {
-    const int g = S.hg[0], steps = S.hs[0], cur = S.hi[0];
+    const QEnt top = S.hq[0];
+    const int g = top.g, steps = top.s, cur = top.i;
     const int prev_dir = S.hd[0];
     heap_size--;
     if (heap_size > 0) {
-      S.hf[0] = S.hf[heap_size]; S.hg[0] = S.hg[heap_size]; S.hs[0] = S.hs[heap_size]; S.hi[0] = S.hi[heap_size];
+      // replace the root with the last entry and sift down (strict '<' on f, left child first)
+      QEnt x = S.hq[heap_size];
       S.hd[0] = S.hd[heap_size];
-      int idx = 0;  // heap_sift_down
+      int idx = 0;
       for (;;) {
-        int left = 2 * idx + 1, right = left + 1, smallest = idx;
-        if (left < heap_size && S.hf[left] < S.hf[smallest]) smallest = left;
-        if (right < heap_size && S.hf[right] < S.hf[smallest]) smallest = right;
+        int left = 2 * idx + 1, right = left + 1;
+        if (left >= heap_size) break;
+        QEnt l = S.hq[left];
+        int smallest = idx;
+        int fs = x.f;
+        QEnt c = x;
+        if (l.f < fs) { smallest = left; fs = l.f; c = l; }
+        if (right < heap_size) {
+          QEnt r = S.hq[right];
+          if (r.f < fs) { smallest = right; c = r; }
+        }
         if (smallest == idx) break;
-        heap_swap(S, idx, smallest);
+        S.hq[idx] = c;     // the child moves up; x keeps sinking
         idx = smallest;
       }
+      S.hq[idx] = x;
     }
     if (cur == goal_idx) {
       int len = 0;
       for (int idx = cur; idx != start_idx;) {
-        bool f;
-        uint32_t h = h_probe(S, idx, f);
-        idx = S.hcame[h];
+        bool f; HEnt e;
+        h_probe(S, idx, f, e);
+        idx = e.came;
         len++;
       }
       if (len > out_cap) return -1;
       int k = len;
       for (int idx = cur; idx != start_idx;) {
         out[--k] = idx;
-        bool f;
-        uint32_t h = h_probe(S, idx, f);
-        idx = S.hcame[h];
+        bool f; HEnt e;
+        h_probe(S, idx, f, e);
+        idx = e.came;
       }
       return len;
     }
-    if (g > h_dist(S, cur)) continue;
+    {
+      bool f; HEnt e;
+      h_probe(S, cur, f, e);
+      if (g > (f ? e.dist : A_INF)) continue;
+    }
     S.expansions++;
     const int cx = cur % W, cy = cur / W;
     const uint8_t bits = d.allowed[cur];
@@ -183,24 +190,26 @@ __device__ int astar_dev(const Dev& d, const TsParams& P, AScratch& S, int start
         else if (rt == 2) ng += P.road_type_penalty_r2;
         else if (rt == 3) ng += P.road_type_penalty_r3;
       }
-      bool found;
-      uint32_t h = h_probe(S, nidx, found);
-      if (ng < (double)(found ? S.hdist[h] : A_INF)) {
+      bool found; HEnt e;
+      uint32_t h = h_probe(S, nidx, found, e);
+      if (ng < (double)(found ? e.dist : A_INF)) {
         S.relaxations++;
         if (!found) {
-          if (S.nodes >= S.cap) return -1;
+          if (S.nodes >= S.node_cap) return -1;
           S.nodes++;
-          S.hstamp[h] = S.epoch; S.hkey[h] = nidx;
         }
-        S.hdist[h] = (int)ng; S.hcame[h] = cur;
+        S.ht[h] = HEnt{nidx, (int)ng, cur, S.epoch};
         if (heap_size >= S.heap_cap) return -1;
+        // heap push at slot heap_size + sift up; dir_arr[slot] is written once and stays with the SLOT
+        QEnt x{(int)(ng + (double)(abs(nx - gx) + abs(ny - gy))), (int)ng, ns, nidx};
         int i = heap_size;
-        S.hf[i] = (int)(ng + (double)(abs(nx - gx) + abs(ny - gy)));
-        S.hg[i] = (int)ng; S.hs[i] = ns; S.hi[i] = nidx; S.hd[i] = (int8_t)dd;
-        while (i > 0) {  // heap_sift_up
+        S.hd[i] = (int8_t)dd;
+        while (i > 0) {
           int parent = (i - 1) / 2;
-          if (S.hf[i] < S.hf[parent]) { heap_swap(S, i, parent); i = parent; } else break;
+          QEnt pe = S.hq[parent];
+          if (x.f < pe.f) { S.hq[i] = pe; i = parent; } else break;
         }
+        S.hq[i] = x;
         heap_size++;
       }
     }
@@ -223,6 +232,7 @@ struct VW {
   bool ax_staged[4];
   int ax_len[4];  // -1 = None
   int d_overtaking, d_detour;
+  bool reach_known;  // d.reach[vid] was computed for this tick's maps and this position
 };
 
 __device__ __forceinline__ int32_t* ax_buf(const AScratch& S, int k) { return k == 0 ? S.OV : k == 1 ? S.PO : k == 2 ? S.DV : S.PD; }
@@ -303,8 +313,16 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
   }
   // ---- phase 1: strict; phase 2: soft obstacles (280-306) ----
   const int sx_goal = v.target;
-  int la = astar_dev(d, P, S, v.pos, sx_goal, false, false, 0x7FFFFFFF, S.A, S.cap);
-  if (la < 0) return false;
+  int la;
+  if (v.reach_known && d.reach[v.vid] == 2) {
+    // k_reach_strict proved the target unreachable under the strict rules: the search would flood its whole
+    // component and return [] (astar_numba.py:239).  Same result, without the flood.
+    S.calls++;
+    la = 0;
+  } else {
+    la = astar_dev(d, P, S, v.pos, sx_goal, false, false, 0x7FFFFFFF, S.A, S.cap);
+    if (la < 0) return false;
+  }
   if (la == 0) {
     la = astar_dev(d, P, S, v.pos, sx_goal, true, false, 0x7FFFFFFF, S.A, S.cap);
     if (la < 0) return false;
@@ -423,6 +441,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
   if (vid < 0) return DV_DONE;
   VW v;
   v.vid = vid; v.i = i; v.pos = d.pos[vid]; v.target = d.target[vid];
+  v.reach_known = S != nullptr;
   v.f = d.flags[vid] & ~VF_EARLY;
   const uint8_t ev = d.ev[vid];
   v.base = d.base_speed[vid]; v.cur = d.cur_speed[vid];
@@ -596,6 +615,36 @@ __global__ void k_decide_replan(Dev d, TsParams P, ATier t, const int32_t* list,
   else if (r == DV_POOL_FULL) retry_list[atomicAdd(&d.cnt->replan_n[3], 1)] = i;
 }
 
+// The same, with the search structures (dist/came_from table and the heap) in LDS: one wave per vehicle, lane 0
+// runs the sequential algorithm.  A* is a chain of dependent accesses; what matters is the latency of each one,
+// and LDS answers several times faster than L2.  Searches that outgrow the LDS budget go to the HBM tiers.
+constexpr int LDS_NODES = 1024, LDS_HASH = 2048, LDS_HEAP = 2048;
+__global__ void __launch_bounds__(64) k_decide_replan_lds(Dev d, TsParams P, ATier cells_tier, const int32_t* list, int begin,
+                                                            int n, int32_t* next_list, int next_counter, int32_t* retry_list) {
+  __shared__ HEnt s_ht[LDS_HASH];
+  __shared__ QEnt s_hq[LDS_HEAP];
+  __shared__ int8_t s_hd[LDS_HEAP];
+  const int j = blockIdx.x;
+  if (j >= n) return;
+  for (int q = threadIdx.x; q < LDS_HASH; q += 64) s_ht[q].stamp = 0;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  AScratch S;
+  scratch_bind(cells_tier, j, S);   // cell buffers (paths) from the arena of the first HBM tier
+  S.ht = s_ht; S.hmask = LDS_HASH - 1; S.hq = s_hq; S.hd = s_hd; S.heap_cap = LDS_HEAP;
+  S.node_cap = LDS_NODES;
+  S.epoch = 0;
+  const int i = list[begin + j];
+  int r = decide_vehicle(d, P, i, &S);
+  if (r == DV_DONE) {
+    atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
+    atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
+    atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
+  }
+  if (r == DV_OVERFLOW) next_list[atomicAdd(&d.cnt->replan_n[next_counter], 1)] = i;
+  else if (r == DV_POOL_FULL) retry_list[atomicAdd(&d.cnt->replan_n[3], 1)] = i;
+}
+
 // one search on the current maps (the `astar(...)` operator seam, ts_astar) - slot 0 of tier `t`
 __global__ void k_astar_single(Dev d, TsParams P, ATier t, int start_idx, int goal_idx, int soft, int ignore_flow,
                                int maximum_steps, int32_t* out_len) {
@@ -623,6 +672,7 @@ __global__ void k_spawn_plan(Dev d, TsParams P, ATier t, int vid, int32_t* statu
   v.f = d.flags[vid]; v.base = 0; v.cur = 0; v.cooldown = P.pathfinding_cooldown;
   v.over_dur = d.over_dur[vid]; v.det_dur = d.det_dur[vid]; v.stuck_ticks = d.stuck_ticks[vid];
   v.newpath = false; v.plen = 0; v.pcur = 0; v.off = 0; v.d_overtaking = 0; v.d_detour = 0;
+  v.reach_known = false;
   for (int k = 0; k < 4; k++) { v.ax_staged[k] = false; v.ax_len[k] = d.ax_len[k][vid]; }
   int len;
   bool ok = compute_path_internal_dev(d, P, S, v, len);
@@ -674,6 +724,58 @@ __global__ void k_pool_gc(Dev d, int n_active, uint32_t* new_pool, unsigned long
     for (int q = 0; q < words; q++) new_pool[dst + q] = d.pool[src + q];
     d.ax_off[k][vid] = dst;
   }
+}
+
+// Strict reachability of the target, one wave per replanning vehicle: a frontier BFS over the same edges the
+// strict A* relaxes (flow bit set, neighbour in bounds, neither occupied nor red).  Unreachable targets are by far
+// the most expensive searches (they flood the component before returning []); the flag lets phase 1 skip them.
+__global__ void k_reach_strict(Dev d, const int32_t* list, int n_list, uint32_t* visited_all, int32_t* queue_all,
+                               size_t words_per, size_t queue_per) {
+  const int w = blockIdx.x;
+  if (w >= n_list) return;
+  const int lane = threadIdx.x;
+  const int i = list[w];
+  const int vid = d.active[i];
+  if (vid < 0) return;
+  uint32_t* visited = visited_all + (size_t)w * words_per;
+  int32_t* queue = queue_all + (size_t)w * queue_per;
+  for (size_t q = lane; q < words_per; q += 64) visited[q] = 0;
+  const int start = d.pos[vid], goal = d.target[vid];
+  const int W = d.W, H = d.H;
+  __syncthreads();
+  if (lane == 0) { queue[0] = start; visited[start >> 5] = 1u << (start & 31); }
+  __syncthreads();
+  int head = 0, tail = 1;
+  bool found = false;
+  while (head < tail && !found) {
+    const int idx = head + lane;
+    const int c = idx < tail ? queue[idx] : -1;
+    head = min(tail, head + 64);
+    const uint8_t bits = c >= 0 ? d.allowed[c] : 0;
+    const int cx = c >= 0 ? c % W : 0, cy = c >= 0 ? c / W : 0;
+    for (int dd = 0; dd < 4; dd++) {
+      int n = -1;
+      if (c >= 0 && (bits & (1 << dd))) {
+        const int nx = cx + (dd == 1) - (dd == 3), ny = cy + (dd == 0) - (dd == 2);
+        if (nx >= 0 && nx < W && ny >= 0 && ny < H) {
+          const int nidx = ny * W + nx;
+          if (d.occ[nidx] != 1 && d.stop[nidx] != 1) {
+            const uint32_t bit = 1u << (nidx & 31);
+            if (!(atomicOr(&visited[nidx >> 5], bit) & bit)) n = nidx;
+          }
+        }
+      }
+      const unsigned long long m = __ballot(n >= 0);
+      if (n >= 0) {
+        const int off = __popcll(m & ((1ULL << lane) - 1));
+        if (tail + off < (int)queue_per) queue[tail + off] = n;
+      }
+      if (__ballot(n == goal && n >= 0)) found = true;
+      tail = min((int)queue_per, tail + (int)__popcll(m));
+    }
+    __syncthreads();  // queue writes of this step are read by the next one
+  }
+  if (lane == 0) d.reach[vid] = found ? 1 : 2;
 }
 
 }  // namespace

@@ -29,7 +29,7 @@ struct DevCnt {
   int deaths;      // vehicles removed this tick
   int need_astar;  // unused (kept for layout)
   int error;       // sticky device-side error
-  int replan_n[6]; // work-list lengths: tier 0, tier 1, tier 2, pool-full retries, beyond the last tier, pad
+  int replan_n[6]; // work-list lengths: first tier, second, third, pool-full retries, beyond the last tier, LDS-tier overflow
   unsigned long long pool_used;  // words handed out from the path pool (device-side bump allocator)
   long long astar_calls, astar_exp, astar_relax;
   int pend_n[2];   // lengths of the two ping-pong lists of still-unresolved schedule slots
@@ -59,6 +59,7 @@ struct Dev {
   int32_t* ax_start[4];
   uint32_t* ax_off[4];
   int32_t* ax_len[4];
+  uint8_t* reach;    // per vehicle, this tick: 0 = unknown, 1 = target reachable under strict rules, 2 = not
   float* density;    // _update_density_map (city_model.py:1764-1778), materialised on demand
   int8_t* occ_snap;  // occupancy at the last tick start (what density_map is a function of)
   int32_t* cell_veh;  // first vehicle in the cell's MultiGrid list, -1 = none

@@ -847,6 +847,9 @@ struct ts_engine {
   int cap_rng_blocks = 0;
   uint32_t *h_rollD = nullptr, *h_Tcum = nullptr;
   int roll_guess = 0;
+  uint32_t* bfs_visited = nullptr;   // k_reach_strict scratch: per wave a visited bitmap and a queue
+  int32_t* bfs_queue = nullptr;
+  int bfs_slots = 0;
   uint8_t *d_take = nullptr, *h_take = nullptr;   // take table of the stream range the next pass will walk
   size_t cap_take = 0;
   uint64_t take_guess = 0;
@@ -858,7 +861,7 @@ struct ts_engine {
   std::vector<void*> allocs;
   // per-kernel HIP-event timing (ts_profile_*)
   // replanning: work lists, scratch tiers, density state, host-side _path_cache
-  int32_t* replan_list[4] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t* replan_list[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [4] = input of the LDS tier
   int cap_replan = 0;
   ATier tier[3];
   bool tier_ready[3] = {false, false, false};
@@ -881,9 +884,9 @@ namespace {
 
 typedef ts_engine E;
 
-enum { PK_DECIDE_PRE = 0, PK_DECIDE_MAIN, PK_MOVE_CLAIM, PK_MOVE_RESOLVE, PK_COMPACT, PK_EVENT, PK_REPLAN, PK_DENSITY, PK_RNG, PH_SCAN, PH_SHUFFLE, PH_SHUFFLE_WAIT, PH_DECIDE_WALL, PH_MOVE_WALL, PH_WAIT1, PH_WORDS, PH_WAIT3, PH_NEED, PK_COUNT };
+enum { PK_DECIDE_PRE = 0, PK_DECIDE_MAIN, PK_MOVE_CLAIM, PK_MOVE_RESOLVE, PK_COMPACT, PK_EVENT, PK_REPLAN, PK_DENSITY, PK_RNG, PK_REACH, PH_SCAN, PH_SHUFFLE, PH_SHUFFLE_WAIT, PH_DECIDE_WALL, PH_MOVE_WALL, PH_WAIT1, PH_WORDS, PH_WAIT3, PH_NEED, PK_COUNT };
 const char* PK_NAMES[PK_COUNT] = {"k_decide_pre", "k_decide_main", "k_move_claim", "k_move_resolve",
-                                  "k_compact", "k_apply_event", "k_decide_replan", "k_density", "k_rng",
+                                  "k_compact", "k_apply_event", "k_decide_replan", "k_density", "k_rng", "k_reach_strict",
                                   "host_rng_scan", "host_shuffle", "host_shuffle_wait", "host_decide_wall", "host_move_wall",
                                   "host_wait_pass1", "host_words_upload", "host_wait_pass3", "host_words_need"};
 
@@ -959,13 +962,14 @@ int ensure_vehicle_capacity(E* e, int need_v, int need_sched) {
 #define RG(field) { int rc = regrow(e, &d.field, k, (size_t)nc); if (rc) return rc; }
     RG(pos) RG(target) RG(path_len) RG(path_cur) RG(stuck_ticks) RG(cooldown) RG(stranded_left) RG(steps) RG(over_dur)
     RG(det_dur) RG(next_in_cell) RG(active_idx) RG(sched_slot) RG(path_off) RG(base_speed) RG(cur_speed) RG(max_steps)
-    RG(dir) RG(pop) RG(flags) RG(depart) RG(ev) RG(st_before) RG(st_after) RG(ev_idx)
+    RG(dir) RG(pop) RG(flags) RG(depart) RG(ev) RG(st_before) RG(st_after) RG(ev_idx) RG(reach)
     for (int k = 0; k < 4; k++) { RG(ax_start[k]) RG(ax_off[k]) RG(ax_len[k]) }
 #undef RG
     { int rc = regrow(e, &e->replan_list[0], 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &e->replan_list[1], 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &e->replan_list[2], 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &e->replan_list[3], 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &e->replan_list[4], 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &d.active, (size_t)e->n_active, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &e->active_alt, 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &d.F, 0, (size_t)nc); if (rc) return rc; }
@@ -1089,13 +1093,12 @@ int ensure_tier(E* e, int t) {
   T.hsize = hs;
   T.heap_cap = (int)std::min<long long>(4ll * T.cap, 0x7FFFFFF0ll);
   const size_t S = (size_t)T.n_slots;
-  HIPOK(dalloc(e, &T.hkey, S * hs)); HIPOK(dalloc(e, &T.hdist, S * hs)); HIPOK(dalloc(e, &T.hcame, S * hs));
-  HIPOK(dalloc(e, &T.hstamp, S * hs));
-  HIPOK(dalloc(e, &T.hf, S * T.heap_cap)); HIPOK(dalloc(e, &T.hg, S * T.heap_cap)); HIPOK(dalloc(e, &T.hs, S * T.heap_cap));
-  HIPOK(dalloc(e, &T.hi, S * T.heap_cap)); HIPOK(dalloc(e, &T.hd, S * T.heap_cap));
+  HIPOK(dalloc(e, &T.ht, S * hs));
+  HIPOK(dalloc(e, &T.hq, S * T.heap_cap));
+  HIPOK(dalloc(e, &T.hd, S * T.heap_cap));
   HIPOK(dalloc(e, &T.cells, S * ((size_t)5 * T.cap + 3 * MAXB)));
   HIPOK(dalloc(e, &T.slot_epoch, S));
-  HIPOK(hipMemsetAsync(T.hstamp, 0, S * hs * 4, e->stream));
+  HIPOK(hipMemsetAsync(T.ht, 0, S * hs * sizeof(HEnt), e->stream));
   HIPOK(hipMemsetAsync(T.slot_epoch, 0, S * 4, e->stream));
   HIPOK(hipStreamSynchronize(e->stream));
   e->tier_ready[t] = true;
@@ -1153,27 +1156,57 @@ int pool_make_room(E* e, size_t need_free) {
 }
 
 // k_decide_replan over the work lists: tier 0 -> overflow to tier 1 -> tier 2; pool-full entries are retried
+inline double now_ms();
 int run_replans(E* e, int n0) {
   Dev& d = e->d;
   const TsParams& P = e->P;
   hipStream_t st = e->stream;
   while (n0 > 0) {
     if (!e->density_valid) { int rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
+    {  // strict reachability of every replanner's target (skips the searches that would flood and fail)
+      const size_t words_per = ((size_t)e->N + 31) / 32, queue_per = (size_t)e->N;
+      if (!e->bfs_visited) {
+        size_t per = words_per * 4 + queue_per * 4;
+        e->bfs_slots = (int)std::max<size_t>(8, std::min<size_t>(2048, (3ull << 30) / per));
+        HIPOK(dalloc(e, &e->bfs_visited, words_per * e->bfs_slots));
+        HIPOK(dalloc(e, &e->bfs_queue, queue_per * e->bfs_slots));
+      }
+      for (int begin = 0; begin < n0; begin += e->bfs_slots) {
+        int cnt = std::min(e->bfs_slots, n0 - begin);
+        LAUNCH(e, PK_REACH, cnt, k_reach_strict, dim3(cnt), dim3(64), d, e->replan_list[0] + begin, cnt, e->bfs_visited,
+               e->bfs_queue, words_per, queue_per);
+      }
+    }
+    // stage 0: search structures in LDS (one wave per vehicle); stages 1-3: the HBM tiers for what outgrows it
+    struct Stage { int tier; int in_list; int out_list; int out_counter; };
+    const Stage stages[4] = {{-1, 0, 4, 5}, {0, 4, 1, 1}, {1, 1, 2, 2}, {2, 2, 3, 4}};
     int n = n0;
-    for (int t = 0; t < 3 && n > 0; t++) {
+    for (int sidx = 0; sidx < 4 && n > 0; sidx++) {
+      const Stage& sg = stages[sidx];
+      const int t = sg.tier < 0 ? 0 : sg.tier;   // the LDS stage borrows the first tier's cell buffers
       int rc = ensure_tier(e, t);
       if (rc) return rc;
-      d.density = e->d.density;
       const ATier& T = e->tier[t];
       for (int begin = 0; begin < n; begin += T.n_slots) {
         int cnt = std::min(T.n_slots, n - begin);
-        LAUNCH(e, PK_REPLAN, cnt, k_decide_replan, dim3(nblk(cnt, 64)), dim3(64), d, P, T, e->replan_list[t], begin, cnt,
-               t < 2 ? e->replan_list[t + 1] : e->replan_list[3], t < 2 ? t + 1 : 4, e->replan_list[3]);
+        if (sg.tier < 0)
+          LAUNCH(e, PK_REPLAN, cnt, k_decide_replan_lds, dim3(cnt), dim3(64), d, P, T, e->replan_list[sg.in_list], begin, cnt,
+                 e->replan_list[sg.out_list], sg.out_counter, e->replan_list[3]);
+        else
+          LAUNCH(e, PK_REPLAN, cnt, k_decide_replan, dim3(nblk(cnt, 64)), dim3(64), d, P, T, e->replan_list[sg.in_list], begin,
+                 cnt, e->replan_list[sg.out_list], sg.out_counter, e->replan_list[3]);
       }
       HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
       HIPOK(hipStreamSynchronize(st));
       if (e->hint[8 + 4] > 0) return fail(e, TS_E_CAPACITY, "an A* search exceeded the largest scratch tier");
-      n = t < 2 ? e->hint[8 + t + 1] : 0;
+      if (getenv("TS_DEBUG_REPLAN")) {
+        static double tlast = 0; double tn = now_ms();
+        fprintf(stderr, "[replan] tick %lld stage %d: in=%d overflow=%d retry=%d dt=%.2f ms\n", (long long)e->C.step_count, sidx, n,
+                e->hint[8 + sg.out_counter], e->hint[8 + 3], tlast ? tn - tlast : 0.0);
+        tlast = tn;
+      }
+      n = e->hint[8 + sg.out_counter];
+      if (sidx == 3) n = 0;
     }
     int retry = e->hint[8 + 3];
     if (retry == 0) break;
