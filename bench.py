@@ -148,6 +148,15 @@ def main():
         bytes_per_launch = ALGO_BYTES[dom] * veh_steps_local / max(launches, 1)
         avg_launch_s = ms / 1e3 / max(launches, 1)
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # HBM traffic per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs of
+        # this same command: FETCH_SIZE, WRITE_SIZE in KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+        # for gfx950 - verified here on k_rank_invert, whose coalesced 4-byte reads report exactly half)
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc_path) and args.size == 4096 and args.vehicles == 1_000_000 and args.policy == "config2":
+            pmc = json.load(open(pmc_path)).get(dom)
+            if pmc:
+                traffic = (2.0 * pmc["fetch_kb_avg"] + pmc["write_kb_avg"]) * 1024.0
         out = {
             "metric": "agent_steps_per_sec", "value": steps_done / elapsed, "unit": "agent-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,7 +177,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_agent_step": ALGO_BYTES[dom], "avg_launch_us": avg_launch_s * 1e6,
                 "launches": launches,
             },

@@ -1,0 +1,205 @@
+"""Edge cases on the GPU, HIP engine vs CPU oracle through the same C-ABI calls: empty and ragged inputs,
+cells holding several vehicles, spawns between ticks (capacity growth, planner + path cache), host writes
+between ticks, populations that die out, parameter extremes, error codes."""
+import numpy as np
+import pytest
+
+from trafficsimulation_amd import _capi as capi
+from trafficsimulation_amd import citygen
+from trafficsimulation_amd.world import build_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def engines():
+    from oracle import pyoracle
+    from trafficsimulation_amd._lib import new_engine
+    return new_engine(), pyoracle.load()
+
+
+def same_state(h, c, ctx=""):
+    for which in (capi.MAP_OCCUPANCY, capi.MAP_STOP, capi.MAP_STUCK):
+        assert np.array_equal(h.map(which), c.map(which)), f"{ctx}: map {which}"
+    a, b = h.vehicles(), c.vehicles()
+    assert a.shape == b.shape, f"{ctx}: {a.shape} vs {b.shape}"
+    if not np.array_equal(a, b):
+        r, col = np.argwhere(a != b)[0]
+        raise AssertionError(f"{ctx}: vehicle row {r} field {capi.V_FIELDS[col]}: hip {a[r, col]} cpu {b[r, col]}")
+    assert np.array_equal(h.groups(), c.groups()), f"{ctx}: groups"
+    assert h.rng_fingerprint(capi.RNG_GLOBAL) == c.rng_fingerprint(capi.RNG_GLOBAL), f"{ctx}: global RNG"
+    assert h.rng_fingerprint(capi.RNG_SCHEDULER) == c.rng_fingerprint(capi.RNG_SCHEDULER), f"{ctx}: scheduler RNG"
+    assert h.num_scheduled() == c.num_scheduled()
+
+
+def both(fn):
+    h, c = engines()
+    try:
+        fn(h), fn(c)
+    except Exception:
+        h.close(), c.close()
+        raise
+    return h, c
+
+
+def world(size=96, seed=3):
+    return citygen.generate(size, size, seed=seed)
+
+
+def test_empty_world_lights_only():
+    """No vehicles at all: light groups still step in shuffled order and the scheduler stream advances."""
+    tb = world()
+    h, c = both(lambda e: build_engine(e, tb, defaults={"RAIN_ENABLED": False}, global_seed=5, sched_seed=6))
+    for t in range(12):
+        h.step(1), c.step(1)
+        same_state(h, c, f"tick {t}")
+    assert h.num_vehicles() == 0 and h.counters().agent_steps == 0
+    h.close(), c.close()
+
+
+def test_no_groups_no_clock_single_vehicle_until_it_despawns():
+    tb = dict(world())
+    G = len(tb["g_light_off"]) - 1
+    tb["schedule_kinds0"] = np.zeros(0, np.int8)  # nothing scheduled but vehicles
+    s, g, off, dirs = citygen.make_routes(tb, 1, seed=4, min_len=8, max_len=8)
+    def mk(e):
+        build_engine(e, tb, defaults={"TRAFFIC_LIGHT_AGENT_ALGORITHM": "DISABLED", "RAIN_ENABLED": False}, global_seed=1, sched_seed=2)
+        e.add_vehicles_dirs(s, g, [capi.POP["through"]], off, dirs)
+    h, c = both(mk)
+    for t in range(14):
+        h.step(1), c.step(1)
+        same_state(h, c, f"tick {t}")
+    assert h.num_vehicles() == 0 and h.counters().count_completed_through == 1
+    h.step(3), c.step(3)          # stepping an empty schedule is fine
+    same_state(h, c, "after")
+    h.close(), c.close()
+
+
+def test_ragged_paths_and_cells_with_several_vehicles():
+    """Vehicles with an empty path, several vehicles spawned on one cell (MultiGrid list order), mixed lengths."""
+    tb = world()
+    s, g, off, dirs = citygen.make_routes(tb, 60, seed=9, min_len=3, max_len=40)
+    sx = citygen.dirs_to_xy(s, off, dirs)
+    starts, goals, poff, pxy = [], [], [0], []
+    for i in range(len(s)):
+        k = 3 if i < 6 else 1          # the first six start cells hold three vehicles each
+        for rep in range(k):
+            starts.append(s[i]); goals.append(g[i])
+            seg = sx[off[i]:off[i + 1]] if (i + rep) % 5 else sx[0:0]   # every fifth gets an empty path
+            pxy.extend(seg.tolist()); poff.append(len(pxy))
+    pol = {"TRAFFIC_LIGHT_AGENT_ALGORITHM": "QUEUE_ACTUATED", "PATHFINDING_COOLDOWN": 10 ** 9,
+           "VEHICLE_STUCK_RECOMPUTE_THRESHOLD": 10 ** 9, "VEHICLE_STUCK_RECOMPUTE_THRESHOLD_INTERSECTION": 10 ** 9,
+           "VEHICLE_CONTRAFLOW_OVERTAKE_ACTIVE": False, "VEHICLE_STUCK_CONTRAFLOW_ENABLED": False,
+           "VEHICLE_MALFUNCTION_CHANCE": 0.0, "VEHICLE_SIDESWIPE_COLLISION_CHANCE": 0.0, "RAIN_ENABLED": False}
+    def mk(e):
+        build_engine(e, tb, defaults=pol, global_seed=11, sched_seed=12)
+        e.add_vehicles(starts, goals, np.full(len(starts), capi.POP["internal"], np.int32), poff,
+                       np.asarray(pxy, np.int32).reshape(-1, 2))
+    h, c = both(mk)
+    same_state(h, c, "spawn")
+    for t in range(40):
+        h.step(1), c.step(1)
+        same_state(h, c, f"tick {t}")
+    h.close(), c.close()
+
+
+def test_spawns_between_ticks_with_planner_cache_and_capacity_growth():
+    """VehicleAgent(...) between ticks without a path: the engine plans (cache hit or A* phases 1-4) on the maps
+    as they are; batches push the vehicle arrays past their initial capacity."""
+    tb = world(128, 7)
+    rng = np.random.RandomState(3)
+    road = np.argwhere((tb["is_road_map"] == 1) & (tb["intersection_map"] == 0))
+    def pick(n):
+        a = road[rng.choice(len(road), n, replace=False)][:, ::-1]
+        b = road[rng.choice(len(road), n, replace=False)][:, ::-1]
+        keep = (a != b).any(axis=1)
+        return a[keep].astype(np.int32), b[keep].astype(np.int32)
+    batches = [pick(700), pick(500), pick(40)]
+    batches[2] = (np.concatenate([batches[2][0], batches[0][0][:20]]), np.concatenate([batches[2][1], batches[0][1][:20]]))  # cache hits
+    pol = {"RAIN_ENABLED": False, "VEHICLE_MALFUNCTION_CHANCE": 0.0, "VEHICLE_SIDESWIPE_COLLISION_CHANCE": 0.0,
+           "PATHFINDING_COOLDOWN": 10 ** 9, "VEHICLE_STUCK_RECOMPUTE_THRESHOLD": 10 ** 9,
+           "VEHICLE_STUCK_RECOMPUTE_THRESHOLD_INTERSECTION": 10 ** 9}
+    h, c = both(lambda e: build_engine(e, tb, defaults=pol, global_seed=21, sched_seed=22))
+    for bi, (a, b) in enumerate(batches):
+        for e in (h, c):
+            e.add_vehicles(a, b, np.full(len(a), capi.POP["through"], np.int32))
+        same_state(h, c, f"batch {bi} spawn")
+        assert h.counters().astar_calls == c.counters().astar_calls
+        for t in range(6):
+            h.step(1), c.step(1)
+            same_state(h, c, f"batch {bi} tick {t}")
+    h.close(), c.close()
+
+
+def test_host_writes_between_ticks_and_rain():
+    """UI handlers write stop_map directly (cell.py:241-251) and RainManager writes rain_map (rain.py:156-184)."""
+    tb = world()
+    s, g, off, dirs = citygen.make_routes(tb, 150, seed=5, min_len=20, max_len=60)
+    pol = {"RAIN_ENABLED": True, "PATHFINDING_COOLDOWN": 10 ** 9, "VEHICLE_STUCK_RECOMPUTE_THRESHOLD": 10 ** 9,
+           "VEHICLE_STUCK_RECOMPUTE_THRESHOLD_INTERSECTION": 10 ** 9, "VEHICLE_CONTRAFLOW_OVERTAKE_ACTIVE": False,
+           "VEHICLE_STUCK_CONTRAFLOW_ENABLED": False, "VEHICLE_MALFUNCTION_CHANCE": 0.0, "VEHICLE_SIDESWIPE_COLLISION_CHANCE": 0.0}
+    def mk(e):
+        build_engine(e, tb, defaults=pol, global_seed=31, sched_seed=32)
+        e.add_vehicles_dirs(s, g, np.full(len(s), capi.POP["through"], np.int32), off, dirs)
+    h, c = both(mk)
+    H, W = tb["is_road_map"].shape
+    rain = np.zeros((H, W), np.int8); rain[:, : W // 2] = 1
+    for t in range(30):
+        if t == 5:
+            for e in (h, c):
+                e.upload_map(capi.MAP_RAIN, rain)
+        if t == 12:      # "all lights stop" from the UI
+            st = h.map(capi.MAP_STOP).copy()
+            for xy in np.asarray(tb["light_xy"]).reshape(-1, 2):
+                st[xy[1], xy[0]] = 1
+            for xy in np.asarray(tb["light_ctrl_xy"]).reshape(-1, 2):
+                st[xy[1], xy[0]] = 1
+            for e in (h, c):
+                e.upload_map(capi.MAP_STOP, st)
+        h.step(1), c.step(1)
+        same_state(h, c, f"tick {t}")
+    h.close(), c.close()
+
+
+def test_parameter_extremes():
+    """min speed == max speed (getrandbits(1) retries), awareness range 1, everyone malfunctions when the feature
+    flag is off (vehicle_base.py:609)."""
+    tb = world()
+    s, g, off, dirs = citygen.make_routes(tb, 120, seed=6, min_len=10, max_len=50)
+    for pol in ({"VEHICLE_MIN_SPEED": 3, "VEHICLE_MAX_SPEED": 3, "VEHICLE_AWARENESS_RANGE": 1},
+                {"VEHICLE_MALFUNCTION_ACTIVE": False, "VEHICLE_MALFUNCTION_DURATION": 3},
+                {"VEHICLE_MIN_SPEED": 1, "VEHICLE_MAX_SPEED": 7}):
+        base = {"RAIN_ENABLED": False, "PATHFINDING_COOLDOWN": 10 ** 9, "VEHICLE_STUCK_RECOMPUTE_THRESHOLD": 10 ** 9,
+                "VEHICLE_STUCK_RECOMPUTE_THRESHOLD_INTERSECTION": 10 ** 9, "VEHICLE_CONTRAFLOW_OVERTAKE_ACTIVE": False,
+                "VEHICLE_STUCK_CONTRAFLOW_ENABLED": False, "TRAFFIC_LIGHT_AGENT_ALGORITHM": "FIXED_TIME"}
+        base.update(pol)
+        def mk(e):
+            build_engine(e, tb, defaults=base, global_seed=41, sched_seed=42)
+            e.add_vehicles_dirs(s, g, np.full(len(s), capi.POP["through"], np.int32), off, dirs)
+        h, c = both(mk)
+        for t in range(15):
+            h.step(1), c.step(1)
+            same_state(h, c, f"{pol} tick {t}")
+        h.close(), c.close()
+
+
+def test_error_codes_match():
+    tb = world()
+    h, c = both(lambda e: build_engine(e, tb, defaults={}, global_seed=None, sched_seed=None))
+    for e in (h, c):
+        with pytest.raises(capi.EngineError) as ei:
+            e.step(1)                       # not seeded
+        assert ei.value.code == capi.TS_E_STATE
+        e.seed_int(capi.RNG_GLOBAL, 1); e.seed_int(capi.RNG_SCHEDULER, 1)
+        with pytest.raises(capi.EngineError) as ei:
+            e.add_vehicles([[-1, 5]], [[20, 20]], [0], [0, 0], np.zeros((0, 2), np.int32))
+        assert ei.value.code == capi.TS_E_INVALID
+        with pytest.raises(capi.EngineError) as ei:   # not a 4-adjacent chain
+            e.add_vehicles([[20, 20]], [[25, 25]], [0], [0, 1], [[22, 20]])
+        assert ei.value.code == capi.TS_E_INVALID
+        with pytest.raises(capi.EngineError) as ei:
+            e.upload_map(capi.MAP_OCCUPANCY, np.zeros(tb["is_road_map"].shape, np.int8))
+        assert ei.value.code == capi.TS_E_INVALID
+    with pytest.raises(capi.EngineError) as ei:       # the engine refuses what it cannot reproduce exactly
+        h.add_vehicles([[20, 20]], [[20, 20]], [0], [0, 0], np.zeros((0, 2), np.int32))
+    assert ei.value.code == capi.TS_E_UNSUPPORTED
+    h.close(), c.close()
