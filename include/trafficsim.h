@@ -164,6 +164,31 @@ enum {
   TS_AGENT_CLOCK = 3        /* DynamicTrafficAgent with empty schedule: elapsed += dt (dynamic_traffic_generator.py:153-155) */
 };
 
+/* DynamicTrafficAgent (dynamic_traffic_generator.py:71-150, 307-430): the daily trip schedule and the mid-tick
+ * spawning of internal / through vehicles.  Service vehicles are not covered (their quotas must be 0). */
+typedef struct TsTrafficZone {      /* one entry of Defaults.TIME_ZONES (config.py:155-236) */
+  int32_t start_hour, end_hour;
+  double through_distribution;
+  int32_t n_internal;               /* entries of internal_distribution, in dict order */
+  int32_t origin_type[8], dest_type[8]; /* index into Defaults.AVAILABLE_CITY_BLOCKS (Res 0, Off 1, Mar 2, Lei 3, Oth 4) */
+  double fraction[8];
+} TsTrafficZone;
+typedef struct TsTrafficTables {
+  int32_t n_blocks;                 /* city_blocks in dict order (what get_city_blocks_by_type iterates) */
+  const int32_t* blk_type;          /* [n_blocks] */
+  const int32_t* blk_entr_off;      /* [n_blocks+1] CityBlock.get_entrances() */
+  const int32_t* blk_entr_xy;
+  int32_t n_highway_entrances;      /* city.get_highway_entrances() / get_highway_exits() */
+  const int32_t* highway_entrances_xy;
+  int32_t n_highway_exits;
+  const int32_t* highway_exits_xy;
+  int32_t internal_population_per_day;  /* INTERNAL_POPULATION_TRAFFIC_PER_DAY */
+  int32_t passing_population_per_day;   /* PASSING_POPULATION_TRAFFIC_PER_DAY */
+  int32_t start_offset_seconds;         /* SIMULATION_STARTING_TIME_OF_DAY_* in seconds */
+  int32_t n_zones;
+  TsTrafficZone zones[8];
+} TsTrafficTables;
+
 /* dynamic_traffic_generator.py:102-131 counters that the hot path writes. */
 typedef struct TsCounters {
   int64_t stuck, collisions, malfunctions, overtaking, in_stuck_detour, parked;
@@ -179,6 +204,7 @@ typedef struct TsCounters {
   int64_t astar_calls, astar_expansions, astar_relaxations;
   int64_t move_rounds;         /* dependency-resolution rounds executed by the move phase */
   int64_t rng_fixups;          /* decide-phase re-scans caused by malfunction/collision events */
+  int64_t created_internal, created_through; /* DynamicTrafficAgent.created_* (reset at day rollover) */
 } TsCounters;
 
 /* One row per live vehicle, in `active_vehicle_agents` order (city_model.py:1903). */
@@ -222,6 +248,11 @@ int ts_set_lights(ts_handle h, const TsLightTables* t);
 
 /* schedule.add() for non-vehicle agents, in insertion order (city_model.py:1642, 1738, 200, 204). */
 int ts_schedule_add(ts_handle h, int32_t kind, int32_t count);
+
+/* DynamicTrafficAgent.__init__ (dynamic_traffic_generator.py:71-150): arms the spawner behind the TS_AGENT_CLOCK
+ * schedule entry and generates day 0, which DRAWS FROM THE GLOBAL STREAM (random(), choice()) - call it after
+ * seeding TS_RNG_GLOBAL, at the point where the reference constructs the agent (end of CityModel.__init__). */
+int ts_set_traffic_generator(ts_handle h, const TsTrafficTables* t);
 
 /* random.setstate() for the two MT19937 streams: TS_RNG_GLOBAL = module-level `random`
  * (vehicle_base.py:112, 600, 609), TS_RNG_SCHEDULER = model.random (city_model.py:55, 1858).

@@ -168,6 +168,17 @@ struct Group {
   int ns_pressure = 0, ew_pressure = 0;
 };
 
+struct Trip { int origin, dest; double depart; int kind; };  // kind: TS_POP_INTERNAL / TS_POP_THROUGH
+struct Generator {
+  bool armed = false;
+  TsTrafficTables T;
+  std::vector<int> blk_type;
+  std::vector<std::vector<int>> blk_entr;  // entrance cells per block
+  std::vector<int> hw_in, hw_out;
+  std::vector<Trip> pending;
+  int current_day = 0;
+};
+
 struct SchedEntry {
   int kind;  // TS_AGENT_* or 100 = vehicle
   int ref;
@@ -197,6 +208,7 @@ struct ts_engine {
   bool seeded[2] = {false, false};
   TsCounters C;
   std::unordered_map<uint64_t, std::vector<int>> path_cache;  // city._path_cache
+  Generator gen;
   std::string err;
   // A* scratch (epoch-stamped so the O(N) init of astar_numba.py:119-122 is not repeated)
   std::vector<int> a_dist, a_came, a_epoch;
@@ -882,6 +894,72 @@ void group_step(E* e, int gi) {  // IntersectionLightGroup.step (396-423)
   g.pending_phase = -1;
 }
 
+// ------------------------------ traffic generator ----------------------------------------------
+extern "C" int tso_add_vehicles(ts_handle e, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
+                                const int32_t* population_type, const int32_t* path_off, const int32_t* path_xy);
+
+// _generate_day (dynamic_traffic_generator.py:307-396) for internal and through trips
+void generate_day(E* e, int day_idx) {
+  Generator& G = e->gen;
+  for (int zi = 0; zi < G.T.n_zones; zi++) {
+    const TsTrafficZone& z = G.T.zones[zi];
+    const double z0 = (double)((long long)day_idx * 86400 + (long long)z.start_hour * 3600 - G.T.start_offset_seconds);
+    const double z1 = (double)((long long)day_idx * 86400 + (long long)z.end_hour * 3600 - G.T.start_offset_seconds);
+    const double span = z1 - z0;
+    for (int k = 0; k < z.n_internal; k++) {
+      long long cnt = (long long)std::nearbyint((double)G.T.internal_population_per_day * z.fraction[k]);  // round()
+      if (cnt == 0) continue;
+      std::vector<int> origins, dests;   // city.get_city_blocks_by_type (city_model.py:2040-2055)
+      for (size_t b = 0; b < G.blk_type.size(); b++) {
+        if (G.blk_type[b] == z.origin_type[k]) origins.push_back((int)b);
+        if (G.blk_type[b] == z.dest_type[k]) dests.push_back((int)b);
+      }
+      if (origins.empty() || dests.empty()) continue;
+      for (long long q = 0; q < cnt; q++) {
+        double t = z0 + e->rng_global.random() * span;
+        int ob = origins[e->rng_global.randbelow((uint32_t)origins.size())];
+        int db = dests[e->rng_global.randbelow((uint32_t)dests.size())];
+        int oc = G.blk_entr[ob][e->rng_global.randbelow((uint32_t)G.blk_entr[ob].size())];
+        int dc = G.blk_entr[db][e->rng_global.randbelow((uint32_t)G.blk_entr[db].size())];
+        G.pending.push_back(Trip{oc, dc, t, TS_POP_INTERNAL});
+      }
+    }
+    // service quotas are zero here (TOTAL_SERVICE_VEHICLES_* = 0): no draws
+    long long thr = (long long)std::nearbyint((double)G.T.passing_population_per_day * z.through_distribution);
+    if (thr < 0) thr = 0;
+    for (long long q = 0; q < thr; q++) {
+      double t = z0 + e->rng_global.random() * span;
+      int ent = G.hw_in[e->rng_global.randbelow((uint32_t)G.hw_in.size())];
+      int ex = G.hw_out[e->rng_global.randbelow((uint32_t)G.hw_out.size())];
+      G.pending.push_back(Trip{ent, ex, t, TS_POP_THROUGH});
+    }
+  }
+}
+
+// DynamicTrafficAgent.step (dynamic_traffic_generator.py:153-194) + _spawn (398-416)
+void generator_step(E* e) {
+  Generator& G = e->gen;
+  const double prev = e->C.elapsed;
+  e->C.elapsed += e->P.time_per_step_seconds;
+  const double total_secs = G.T.start_offset_seconds + e->C.elapsed;
+  const int new_day = (int)std::floor(total_secs / 86400.0);
+  if (new_day > G.current_day) {
+    for (int dd = G.current_day + 1; dd <= new_day; dd++) generate_day(e, dd);
+    G.current_day = new_day;
+    e->C.created_internal = 0; e->C.created_through = 0;
+  }
+  std::vector<Trip> keep, spawn;
+  for (const Trip& t : G.pending) (prev < t.depart && t.depart <= e->C.elapsed ? spawn : keep).push_back(t);
+  for (const Trip& t : spawn) {
+    if (t.kind == TS_POP_INTERNAL) e->C.created_internal++; else e->C.created_through++;
+    (void)e->rng_global.randint(0, 9999);  // the id suffix: vid = f"V_{depart:06d}_{randint(0, 9999):04d}"
+    int32_t s[2] = {t.origin % e->W, t.origin / e->W}, g[2] = {t.dest % e->W, t.dest / e->W};
+    int32_t pop = t.kind;
+    tso_add_vehicles(e, 1, s, g, &pop, nullptr, nullptr);
+  }
+  G.pending.swap(keep);
+}
+
 // ------------------------------ one tick (city_model.py:1831-1860) -----------------------------
 void tick(E* e) {
   // _update_density_map (1853): the map is a function of the occupancy at this point; it is
@@ -931,7 +1009,10 @@ void tick(E* e) {
     switch (se.kind) {
       case 100: vehicle_step(e, se.ref); break;
       case TS_AGENT_LIGHT_GROUP: group_step(e, se.ref); break;
-      case TS_AGENT_CLOCK: e->C.elapsed += e->P.time_per_step_seconds; break;
+      case TS_AGENT_CLOCK:
+        if (e->gen.armed) generator_step(e);
+        else e->C.elapsed += e->P.time_per_step_seconds;
+        break;
       default: break;
     }
   }
@@ -1064,6 +1145,41 @@ int tso_schedule_add(ts_handle e, int32_t kind, int32_t count) {
     } else if (kind != TS_AGENT_NOOP && kind != TS_AGENT_CLOCK) return fail(e, TS_E_INVALID, "bad agent kind");
     e->sched.push_back(se);
   }
+  return TS_OK;
+}
+
+int tso_set_traffic_generator(ts_handle e, const TsTrafficTables* t) {
+  if (!e || !t || t->n_blocks < 0 || t->n_zones < 0 || t->n_zones > 8) return TS_E_INVALID;
+  if (!e->seeded[0]) return fail(e, TS_E_STATE, "seed the global stream before constructing the traffic generator");
+  Generator& G = e->gen;
+  G.T = *t;
+  const int W = e->W, H = e->H;
+  auto cellxy = [&](const int32_t* xy, int i, int& out) {
+    int x = xy[2 * i], y = xy[2 * i + 1];
+    if (x < 0 || x >= W || y < 0 || y >= H) return false;
+    out = y * W + x;
+    return true;
+  };
+  G.blk_type.assign(t->blk_type, t->blk_type + t->n_blocks);
+  G.blk_entr.assign(t->n_blocks, {});
+  for (int b = 0; b < t->n_blocks; b++) {
+    for (int k = t->blk_entr_off[b]; k < t->blk_entr_off[b + 1]; k++) {
+      int c;
+      if (!cellxy(t->blk_entr_xy, k, c)) return fail(e, TS_E_INVALID, "block entrance out of bounds");
+      G.blk_entr[b].push_back(c);
+    }
+    if (G.blk_entr[b].empty()) return fail(e, TS_E_UNSUPPORTED, "a city block without entrances (random.choice([]) raises in the reference)");
+  }
+  G.hw_in.clear(); G.hw_out.clear();
+  for (int k = 0; k < t->n_highway_entrances; k++) { int c; if (!cellxy(t->highway_entrances_xy, k, c)) return TS_E_INVALID; G.hw_in.push_back(c); }
+  for (int k = 0; k < t->n_highway_exits; k++) { int c; if (!cellxy(t->highway_exits_xy, k, c)) return TS_E_INVALID; G.hw_out.push_back(c); }
+  if ((G.hw_in.empty() || G.hw_out.empty()) && t->passing_population_per_day > 0)
+    return fail(e, TS_E_UNSUPPORTED, "through traffic needs highway entrances and exits");
+  for (int z = 0; z < t->n_zones; z++) if (t->zones[z].n_internal < 0 || t->zones[z].n_internal > 8) return TS_E_INVALID;
+  G.pending.clear();
+  G.current_day = 0;
+  G.armed = true;
+  generate_day(e, 0);
   return TS_OK;
 }
 

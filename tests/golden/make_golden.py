@@ -76,6 +76,12 @@ SCENARIOS = {
     # config-5 style: sub-block roads + L-shaped carves
     "carve_96_s10": dict(size=96, seed=10, vehicles=200, ticks=60,
                          defaults={**CLOSED}, model_kwargs=dict(carve_subblock_roads=True)),
+    # "next" row 2: the traffic generator spawning internal + through trips mid-tick (rain and service vehicles off)
+    "dta_64_s12": dict(size=64, seed=12, vehicles=20, ticks=260,
+                       defaults={"RAIN_ENABLED": False, "TOTAL_SERVICE_VEHICLES_FOOD": 0, "TOTAL_SERVICE_VEHICLES_WASTE": 0}),
+    "dta_96_s13": dict(size=96, seed=13, vehicles=40, ticks=160,
+                       defaults={"RAIN_ENABLED": False, "TOTAL_SERVICE_VEHICLES_FOOD": 0, "TOTAL_SERVICE_VEHICLES_WASTE": 0,
+                                 "INTERNAL_POPULATION_TRAFFIC_PER_DAY": 60000, "PASSING_POPULATION_TRAFFIC_PER_DAY": 20000}),
     # config 1: everything on (rain, traffic generator, service vehicles) - "next" rows
     "config1_64_s11": dict(size=64, seed=11, vehicles=50, ticks=100, defaults={}),
 }
@@ -109,6 +115,8 @@ DIRI = {"N": 0, "E": 1, "S": 2, "W": 3, None: -1}
 def world_tables(m):
     """G1: everything the hot path consumes from world-gen."""
     import numpy as np
+    from Simulation.config import Defaults as _D
+    Defaults_AVAILABLE = _D.AVAILABLE_CITY_BLOCKS
     from Simulation.agents.city_structure_entities.intersection_light_group import IntersectionLightGroup
     from Simulation.agents.city_structure_entities.city_block import CityBlock
     out = dict(
@@ -190,6 +198,12 @@ def world_tables(m):
         else:
             kinds.append(4)
     out["schedule_kinds0"] = np.asarray(kinds, dtype=np.int8)
+    # city blocks in city_blocks dict order (what get_city_blocks_by_type iterates): type index into
+    # Defaults.AVAILABLE_CITY_BLOCKS and the entrance cells of each block (CityBlock.get_entrances())
+    blocks = list(getattr(m, "city_blocks", {}).values())
+    types = list(Defaults_AVAILABLE)
+    out["blk_type"] = np.asarray([types.index(b.block_type) for b in blocks], dtype=np.int32)
+    out["blk_entr_off"], out["blk_entr_xy"] = ragged([[c for e in b.get_entrances() for c in e.position] for b in blocks], 2)
     out["block_entrances_xy"] = np.asarray([c.position for c in m.block_entrances], dtype=np.int32).reshape(-1, 2)
     out["highway_entrances_xy"] = np.asarray([c.position for c in m.highway_entrances], dtype=np.int32).reshape(-1, 2)
     out["highway_exits_xy"] = np.asarray([c.position for c in m.highway_exits], dtype=np.int32).reshape(-1, 2)
@@ -205,7 +219,8 @@ GRP_FIELDS = ["current_phase", "pending_phase", "queue_timer", "gap_timer", "las
               "fixed_time_timer", "ft_phase", "ns_pressure", "ew_pressure"]
 CNT_FIELDS = ["stuck", "collisions", "malfunctions", "overtaking", "in_stuck_detour", "parked",
               "live_internal", "live_through", "count_completed_internal", "count_completed_through",
-              "total_distance_internal", "total_distance_through", "errored_internal", "errored_through"]
+              "total_distance_internal", "total_distance_through", "errored_internal", "errored_through",
+              "created_internal", "created_through"]
 
 
 def veh_row(v):
@@ -249,7 +264,22 @@ def run_scenario(name):
     import Simulation.agents.vehicles.vehicle_base as vb
 
     size = spec["size"]
+    # DynamicTrafficAgent.__init__ ends with _generate_day(0), which draws from the global stream inside
+    # CityModel.__init__: remember the state just before it so a replay can generate the same day
+    import Simulation.agents.dynamic_traffic_generator as dtg
+    pre_day0 = {}
+    orig_gen = dtg.DynamicTrafficAgent._generate_day
+
+    def gen_day(self, day_idx):
+        if day_idx == 0 and "st" not in pre_day0:
+            pre_day0["st"] = random.getstate()
+        return orig_gen(self, day_idx)
+    dtg.DynamicTrafficAgent._generate_day = gen_day
     m = CityModel(width=size, height=size, seed=seed, **spec.get("model_kwargs", {}))
+    if "st" in pre_day0:
+        pre = pre_day0["st"][1]
+    else:
+        pre = random.getstate()[1]
     out = world_tables(m)
     out["scenario"] = np.asarray(json.dumps(dict(name=name, **{k: v for k, v in spec.items()})))
     out["defaults_json"] = np.asarray(json.dumps(spec["defaults"]))
@@ -283,6 +313,13 @@ def run_scenario(name):
     exits = m.get_exit_blocks()
     st_after_world = random.getstate()
     out["global_rng_after_worldgen"] = np.asarray(st_after_world[1], dtype=np.uint32)
+    out["global_rng_before_day0"] = np.asarray(pre, dtype=np.uint32)
+    dta0 = getattr(m, "dynamic_traffic_generator", None)
+    out["dta_params"] = np.asarray(json.dumps(dict(
+        P_int=int(Defaults.INTERNAL_POPULATION_TRAFFIC_PER_DAY), P_thr=int(Defaults.PASSING_POPULATION_TRAFFIC_PER_DAY),
+        dt=int(Defaults.TIME_PER_STEP_IN_SECONDS),
+        start_offset=int(Defaults.SIMULATION_STARTING_TIME_OF_DAY_HOURS * 3600 + Defaults.SIMULATION_STARTING_TIME_OF_DAY_MINUTES * 60),
+        pending_day0=(len(dta0.pending) if dta0 is not None else 0))))
     out["sched_rng_initial"] = np.asarray(m.random.getstate()[1], dtype=np.uint32)
     v_start, v_goal, v_path_off, v_path_flat = [], [], [0], []
     vehicles = []

@@ -1,6 +1,7 @@
 """Replay a tests/golden/trace_*.npz fixture on an engine behind the C-ABI and compare every
 tick against the reference's recorded state (maps, per-vehicle tuples, light-group state,
 counters, RNG fingerprints)."""
+import json
 import os
 
 import numpy as np
@@ -20,9 +21,26 @@ def trace_path(name):
     return os.path.join(GOLDEN, f"trace_{name}.npz")
 
 
+DTA_TRACES = ["dta_64_s12", "dta_96_s13"]
+
+
 def setup_from_trace(api, tr, explicit_paths=False):
-    build_engine(api, tr, defaults=tr["defaults_json"], global_state=tr["global_rng_after_worldgen"],
-                 sched_state=tr["sched_rng_initial"])
+    dta = json.loads(str(tr["dta_params"])) if "dta_params" in tr else None
+    if dta and (dta["P_int"] > 0 or dta["P_thr"] > 0):
+        # the traffic generator draws its day-0 schedule inside CityModel.__init__: start from the stream state
+        # just before that and let the engine generate the same day
+        build_engine(api, tr, defaults=tr["defaults_json"], global_state=tr["global_rng_before_day0"],
+                     sched_state=tr["sched_rng_initial"])
+        api.set_traffic_generator(tr, internal_per_day=dta["P_int"], passing_per_day=dta["P_thr"],
+                                  start_offset_seconds=dta["start_offset"])
+        import zlib
+        want = np.asarray(tr["global_rng_after_worldgen"], dtype=np.uint64)
+        got = api.rng_state(capi.RNG_GLOBAL)
+        assert got[1] == int(want[624]) and np.array_equal(got[0], want[:624].astype(np.uint32)), \
+            "day-0 trip generation consumed the global stream differently"
+    else:
+        build_engine(api, tr, defaults=tr["defaults_json"], global_state=tr["global_rng_after_worldgen"],
+                     sched_state=tr["sched_rng_initial"])
     n = len(tr["v_start_xy"])
     pop = np.full(n, capi.POP["through"], dtype=np.int32)
     if explicit_paths:

@@ -80,7 +80,37 @@ class TsCounters(C.Structure):
         "total_distance_through", "errored_internal", "errored_through")] + [
         ("total_duration_internal", C.c_double), ("total_duration_through", C.c_double), ("elapsed", C.c_double)] + [
         (n, C.c_int64) for n in ("step_count", "agent_steps", "astar_calls", "astar_expansions",
-                                 "astar_relaxations", "move_rounds", "rng_fixups")]
+                                 "astar_relaxations", "move_rounds", "rng_fixups", "created_internal",
+                                 "created_through")]
+
+
+class TsTrafficZone(C.Structure):
+    _fields_ = [("start_hour", C.c_int32), ("end_hour", C.c_int32), ("through_distribution", C.c_double),
+                ("n_internal", C.c_int32), ("origin_type", C.c_int32 * 8), ("dest_type", C.c_int32 * 8),
+                ("fraction", C.c_double * 8)]
+
+
+class TsTrafficTables(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("blk_type", C.c_void_p), ("blk_entr_off", C.c_void_p),
+                ("blk_entr_xy", C.c_void_p), ("n_highway_entrances", C.c_int32), ("highway_entrances_xy", C.c_void_p),
+                ("n_highway_exits", C.c_int32), ("highway_exits_xy", C.c_void_p),
+                ("internal_population_per_day", C.c_int32), ("passing_population_per_day", C.c_int32),
+                ("start_offset_seconds", C.c_int32), ("n_zones", C.c_int32), ("zones", TsTrafficZone * 8)]
+
+
+# Defaults.TIME_ZONES (config.py:155-236) with block types as indices into AVAILABLE_CITY_BLOCKS
+_BT = {"Res": 0, "Off": 1, "Mar": 2, "Lei": 3, "Oth": 4}
+DEFAULT_TIME_ZONES = [
+    (6, 9, 0.15, [("Res", "Off", 0.05), ("Res", "Mar", 0.05), ("Res", "Lei", 0.02), ("Res", "Oth", 0.03)]),
+    (9, 12, 0.20, [("Res", "Mar", 0.10), ("Res", "Oth", 0.04), ("Off", "Oth", 0.06)]),
+    (12, 15, 0.15, [("Res", "Mar", 0.07), ("Res", "Oth", 0.03), ("Off", "Oth", 0.05)]),
+    (15, 18, 0.15, [("Res", "Mar", 0.03), ("Off", "Oth", 0.05), ("Mar", "Oth", 0.05), ("Lei", "Oth", 0.02)]),
+    (18, 21, 0.12, [("Res", "Oth", 0.02), ("Res", "Lei", 0.02), ("Off", "Lei", 0.02), ("Mar", "Lei", 0.02),
+                    ("Oth", "Lei", 0.02), ("Mar", "Oth", 0.01), ("Lei", "Oth", 0.01)]),
+    (21, 24, 0.10, [("Off", "Res", 0.03), ("Mar", "Res", 0.03), ("Lei", "Res", 0.02), ("Oth", "Res", 0.02)]),
+    (0, 3, 0.08, [("Off", "Res", 0.02), ("Lei", "Res", 0.04), ("Oth", "Res", 0.01), ("Res", "Lei", 0.01)]),
+    (3, 6, 0.05, [("Res", "Mar", 0.02), ("Res", "Lei", 0.02), ("Res", "Oth", 0.01)]),
+]
 
 
 # Defaults attribute name -> TsParams field (config.py)
@@ -156,6 +186,7 @@ class CApi:
         f("create").argtypes = [C.POINTER(TsWorld), C.POINTER(TsParams), C.POINTER(C.c_void_p)]
         f("set_lights").argtypes = [C.c_void_p, C.POINTER(TsLightTables)]
         f("schedule_add").argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        f("set_traffic_generator").argtypes = [C.c_void_p, C.POINTER(TsTrafficTables)]
         f("seed").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32]
         f("seed_int").argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
         f("rng_state").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_uint32)]
@@ -254,6 +285,30 @@ class CApi:
             setattr(t, k, v.ctypes.data)
         self._chk(self._f("set_lights")(self.h, C.byref(t)))
         self.n_groups = t.n_groups
+
+    def set_traffic_generator(self, tables: dict, internal_per_day=10000, passing_per_day=2400,
+                              start_offset_seconds=6 * 3600, zones=None):
+        """DynamicTrafficAgent.__init__: `tables` carries blk_type / blk_entr_off / blk_entr_xy /
+        highway_entrances_xy / highway_exits_xy (golden world-table keys).  Generates day 0 (global stream)."""
+        t = TsTrafficTables()
+        keep = dict(bt=_i32(tables["blk_type"]), bo=_i32(tables["blk_entr_off"]), bx=_i32(tables["blk_entr_xy"]),
+                    hi=_i32(tables["highway_entrances_xy"]), ho=_i32(tables["highway_exits_xy"]))
+        t.n_blocks = len(keep["bt"])
+        t.blk_type, t.blk_entr_off, t.blk_entr_xy = keep["bt"].ctypes.data, keep["bo"].ctypes.data, keep["bx"].ctypes.data
+        t.n_highway_entrances = len(keep["hi"].reshape(-1, 2))
+        t.highway_entrances_xy = keep["hi"].ctypes.data
+        t.n_highway_exits = len(keep["ho"].reshape(-1, 2))
+        t.highway_exits_xy = keep["ho"].ctypes.data
+        t.internal_population_per_day, t.passing_population_per_day = int(internal_per_day), int(passing_per_day)
+        t.start_offset_seconds = int(start_offset_seconds)
+        zs = zones if zones is not None else DEFAULT_TIME_ZONES
+        t.n_zones = len(zs)
+        for i, (h0, h1, thr, pairs) in enumerate(zs):
+            z = t.zones[i]
+            z.start_hour, z.end_hour, z.through_distribution, z.n_internal = h0, h1, thr, len(pairs)
+            for k, (o, dd, fr) in enumerate(pairs):
+                z.origin_type[k], z.dest_type[k], z.fraction[k] = _BT[o], _BT[dd], fr
+        self._chk(self._f("set_traffic_generator")(self.h, C.byref(t)))
 
     def schedule_add(self, kind: int, count: int = 1):
         self._chk(self._f("schedule_add")(self.h, kind, count))

@@ -147,11 +147,12 @@ __device__ __forceinline__ bool group_reads_neighbors(const TsParams& P) {
 // cr_* = min rank of readers.  Keys carry an epoch prefix that DEcreases every round, so atomicMin
 // makes stale entries of earlier rounds lose and nothing has to be cleared.
 // `list` == nullptr: every schedule slot (first round); otherwise the slots left unresolved by the previous round.
-__global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix, const int32_t* list, const int* list_n) {
+__global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix, const int32_t* list, const int* list_n,
+                             uint32_t rank_limit) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int s;
   if (list) { if (t >= *list_n) return; s = list[t]; } else { s = t; if (s >= n_sched) return; }
-  if (d.resolved[s]) return;
+  if (d.resolved[s] || d.rank[s] >= rank_limit) return;   // rank_limit: agents behind a host-side agent wait for it
   const int8_t kind = d.sched_kind[s];
   const uint32_t key = (prefix << RANK_BITS) | d.rank[s];
   if (kind == K_VEHICLE) {
@@ -396,11 +397,11 @@ __device__ void group_step_dev(const Dev& d, const TsParams& P, int g) {
 
 // An agent steps in this round iff no unresolved agent of lower rank claims a cell it reads or writes.
 __global__ void k_move_resolve(Dev d, TsParams P, int n_sched, uint32_t prefix, uint32_t rank_clock, double elapsed0,
-                               const int32_t* list, const int* list_n, int32_t* out_list, int* out_n) {
+                               const int32_t* list, const int* list_n, int32_t* out_list, int* out_n, uint32_t rank_limit) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int s;
   if (list) { if (t >= *list_n) return; s = list[t]; } else { s = t; if (s >= n_sched) return; }
-  if (d.resolved[s]) return;
+  if (d.resolved[s] || d.rank[s] >= rank_limit) return;
   const int8_t kind = d.sched_kind[s];
   const uint32_t r = d.rank[s];
   bool safe = true;
@@ -838,6 +839,17 @@ struct ts_engine {
   TsCounters C;
   std::vector<uint32_t> perm, shuffle_j;
   int32_t* pend_list[2] = {nullptr, nullptr};
+  // DynamicTrafficAgent (host side): trip schedule + mid-tick spawning behind the clock agent's schedule slot
+  struct Trip { int origin, dest; double depart; int kind; };
+  struct Generator {
+    bool armed = false;
+    TsTrafficTables T;
+    std::vector<int> blk_type;
+    std::vector<std::vector<int>> blk_entr;
+    std::vector<int> hw_in, hw_out;
+    std::vector<Trip> pending;
+    int current_day = 0;
+  } gen;
   // device-side RNG bookkeeping
   uint32_t* h_words = nullptr;        // pinned storage of the global stream's tempered-word ring
   uint64_t words_uploaded = 0;        // absolute word index up to which d.words mirrors it
@@ -879,6 +891,8 @@ struct ts_engine {
   long long prof_launches[24] = {0}, prof_items[24] = {0};
   double shuffle_ms = 0;
 };
+
+static int add_vehicle_planned(ts_handle e, int start, int goal, int pop_type);  // defined with the C-ABI entries
 
 namespace {
 
@@ -1304,6 +1318,70 @@ void shuffle_wait(E* e) {
   e->sh_cv.wait(lk, [e]() { return e->sh_done; });
 }
 
+// _generate_day (dynamic_traffic_generator.py:307-396), internal + through trips; service quotas must be 0
+void generate_day(E* e, int day_idx) {
+  auto& G = e->gen;
+  MTPipe& r = e->rng_global;
+  for (int zi = 0; zi < G.T.n_zones; zi++) {
+    const TsTrafficZone& z = G.T.zones[zi];
+    const double z0 = (double)((long long)day_idx * 86400 + (long long)z.start_hour * 3600 - G.T.start_offset_seconds);
+    const double z1 = (double)((long long)day_idx * 86400 + (long long)z.end_hour * 3600 - G.T.start_offset_seconds);
+    const double span = z1 - z0;
+    for (int k = 0; k < z.n_internal; k++) {
+      const long long cnt = (long long)std::nearbyint((double)G.T.internal_population_per_day * z.fraction[k]);
+      if (cnt == 0) continue;
+      std::vector<int> origins, dests;
+      for (size_t b = 0; b < G.blk_type.size(); b++) {
+        if (G.blk_type[b] == z.origin_type[k]) origins.push_back((int)b);
+        if (G.blk_type[b] == z.dest_type[k]) dests.push_back((int)b);
+      }
+      if (origins.empty() || dests.empty()) continue;
+      for (long long q = 0; q < cnt; q++) {
+        const double t = z0 + r.random() * span;
+        const int ob = origins[r.randbelow((uint32_t)origins.size())];
+        const int db = dests[r.randbelow((uint32_t)dests.size())];
+        const int oc = G.blk_entr[ob][r.randbelow((uint32_t)G.blk_entr[ob].size())];
+        const int dc = G.blk_entr[db][r.randbelow((uint32_t)G.blk_entr[db].size())];
+        G.pending.push_back(ts_engine::Trip{oc, dc, t, TS_POP_INTERNAL});
+      }
+    }
+    long long thr = (long long)std::nearbyint((double)G.T.passing_population_per_day * z.through_distribution);
+    for (long long q = 0; q < thr; q++) {
+      const double t = z0 + r.random() * span;
+      const int ent = G.hw_in[r.randbelow((uint32_t)G.hw_in.size())];
+      const int ex = G.hw_out[r.randbelow((uint32_t)G.hw_out.size())];
+      G.pending.push_back(ts_engine::Trip{ent, ex, t, TS_POP_THROUGH});
+    }
+  }
+}
+
+// DynamicTrafficAgent.step (153-194) and _spawn (398-416), executed at the agent's place in the shuffled order:
+// every lower-ranked agent has stepped on the device, every higher-ranked one has not yet.
+int generator_step(E* e) {
+  auto& G = e->gen;
+  const double prev = e->C.elapsed;
+  e->C.elapsed += e->P.time_per_step_seconds;
+  const double total_secs = G.T.start_offset_seconds + e->C.elapsed;
+  const int new_day = (int)std::floor(total_secs / 86400.0);
+  if (new_day > G.current_day) {
+    for (int dd = G.current_day + 1; dd <= new_day; dd++) generate_day(e, dd);
+    G.current_day = new_day;
+    e->C.created_internal = 0; e->C.created_through = 0;
+  }
+  std::vector<ts_engine::Trip> keep, spawn;
+  for (const auto& t : G.pending) (prev < t.depart && t.depart <= e->C.elapsed ? spawn : keep).push_back(t);
+  G.pending.swap(keep);
+  for (const auto& t : spawn) {
+    if (t.kind == TS_POP_INTERNAL) e->C.created_internal++; else e->C.created_through++;
+    (void)e->rng_global.randint(0, 9999);  // the id suffix of "V_{depart:06d}_{randint(0, 9999):04d}"
+    if (t.origin == t.dest) return fail(e, TS_E_UNSUPPORTED, "generated trip with origin == destination");
+    if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
+    int rc = add_vehicle_planned(e, t.origin, t.dest, t.kind);
+    if (rc) return rc;
+  }
+  return TS_OK;
+}
+
 // mirror the global stream's tempered words [uploaded, upto) into the device ring (copy stream + event)
 int words_upload(E* e, uint64_t upto) {
   MTPipe& r = e->rng_global;
@@ -1504,6 +1582,7 @@ int tick(E* e) {
   host_prof(e, PH_SHUFFLE, e->shuffle_ms, nS);
   const double t_move0 = now_ms();
   const uint32_t rank_clock = e->rank_clock_host;
+  const int sched_vehicles_at_shuffle = e->n_sched_vehicles;
   const double elapsed0 = e->C.elapsed;
   if (nS > 0) {
     HIPOK(hipMemcpyAsync(e->d_perm, e->hrank, (size_t)nS * 4, hipMemcpyHostToDevice, st));
@@ -1511,42 +1590,60 @@ int tick(E* e) {
     HIPOK(hipMemsetAsync(d.resolved, 0, (size_t)nS, st));
     HIPOK(hipMemsetAsync(&d.cnt->resolved, 0, sizeof(int) * 2, st));  // resolved, deaths
     // Round 1 covers every slot; later rounds only the slots that were still blocked (ping-pong lists).
-    int done = 0, round_no = 0, pending_bound = nS;
-    HIPOK(hipMemsetAsync(d.cnt->pend_n, 0, sizeof(int) * 2, st));
-    while (done < nS) {
-      const int chunk = round_no == 0 ? 1 : 4;
-      for (int rr = 0; rr < chunk; rr++, round_no++) {
-        if ((e->epoch % EPOCHS) == 0) {  // epoch prefix wrapped: stale keys would win again -> clear once
-          size_t n = (size_t)e->N;
-          HIPOK(hipMemsetAsync(d.claims, 0xFF, n * 16, st));
-          HIPOK(hipMemsetAsync(d.gclaim_r, 0xFF, (size_t)std::max(d.G, 1) * 4, st));
+    // With an armed traffic generator the phase runs in two parts: first every agent ranked before it, then the
+    // generator's own step on the host (spawns plan on the maps as they are at that point), then the rest.
+    const bool split = e->gen.armed && e->clock_slot >= 0;
+    int done = 0;
+    for (int part = split ? 0 : 1; part < 2; part++) {
+      const uint32_t rank_limit = part == 0 ? rank_clock : NO_RANK;
+      const int target = part == 0 ? (int)rank_clock : nS;
+      int round_no = 0, pending_bound = nS;
+      HIPOK(hipMemsetAsync(d.cnt->pend_n, 0, sizeof(int) * 2, st));
+      while (done < target) {
+        const int chunk = round_no == 0 ? 1 : 4;
+        for (int rr = 0; rr < chunk; rr++, round_no++) {
+          if ((e->epoch % EPOCHS) == 0) {  // epoch prefix wrapped: stale keys would win again -> clear once
+            size_t n = (size_t)e->N;
+            HIPOK(hipMemsetAsync(d.claims, 0xFF, n * 16, st));
+            HIPOK(hipMemsetAsync(d.gclaim_r, 0xFF, (size_t)std::max(d.G, 1) * 4, st));
+          }
+          const uint32_t prefix = (EPOCHS - 1) - (e->epoch % EPOCHS);
+          e->epoch++;
+          const int in = round_no & 1, out = in ^ 1;   // round r reads list[r & 1] (none in round 0), writes the other
+          const int32_t* in_list = round_no == 0 ? nullptr : e->pend_list[in];
+          const int grid_items = round_no == 0 ? nS : pending_bound;
+          HIPOK(hipMemsetAsync(&d.cnt->pend_n[out], 0, sizeof(int), st));
+          LAUNCH(e, PK_MOVE_CLAIM, grid_items, k_move_claim, dim3(nblk(grid_items)), dim3(BLK), d, P, nS, prefix, in_list,
+                 &d.cnt->pend_n[in], rank_limit);
+          LAUNCH(e, PK_MOVE_RESOLVE, grid_items, k_move_resolve, dim3(nblk(grid_items)), dim3(BLK), d, P, nS, prefix,
+                 rank_clock, elapsed0, in_list, &d.cnt->pend_n[in], e->pend_list[out], &d.cnt->pend_n[out], rank_limit);
+          e->C.move_rounds++;
         }
-        const uint32_t prefix = (EPOCHS - 1) - (e->epoch % EPOCHS);
-        e->epoch++;
-        const int in = round_no & 1, out = in ^ 1;   // round r reads list[r & 1] (none in round 0), writes the other
-        const int32_t* in_list = round_no == 0 ? nullptr : e->pend_list[in];
-        const int grid_items = round_no == 0 ? nS : pending_bound;
-        HIPOK(hipMemsetAsync(&d.cnt->pend_n[out], 0, sizeof(int), st));
-        LAUNCH(e, PK_MOVE_CLAIM, grid_items, k_move_claim, dim3(nblk(grid_items)), dim3(BLK), d, P, nS, prefix, in_list,
-               &d.cnt->pend_n[in]);
-        LAUNCH(e, PK_MOVE_RESOLVE, grid_items, k_move_resolve, dim3(nblk(grid_items)), dim3(BLK), d, P, nS, prefix,
-               rank_clock, elapsed0, in_list, &d.cnt->pend_n[in], e->pend_list[out], &d.cnt->pend_n[out]);
-        e->C.move_rounds++;
+        HIPOK(hipMemcpyAsync(e->hint, &d.cnt->resolved, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        int now = e->hint[0];
+        if (now == done && now < target) return fail(e, TS_E_DEVICE, "move phase made no progress (internal error)");
+        done = now;
+        pending_bound = std::max(1, target - done);
       }
-      HIPOK(hipMemcpyAsync(e->hint, &d.cnt->resolved, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
-      HIPOK(hipStreamSynchronize(st));
-      int now = e->hint[0];
-      if (now == done && now < nS) return fail(e, TS_E_DEVICE, "move phase made no progress (internal error)");
-      done = now;
-      pending_bound = std::max(1, nS - done);
+      if (part == 0) {
+        // the generator's turn: DynamicTrafficAgent.step on the host, then mark its slot as stepped
+        int rc = generator_step(e);
+        if (rc) return rc;
+        const uint8_t one = 1;
+        HIPOK(hipMemcpyAsync(d.resolved + e->clock_slot, &one, 1, hipMemcpyHostToDevice, st));
+        done += 1;
+        HIPOK(hipMemcpyAsync(&d.cnt->resolved, &done, sizeof(int), hipMemcpyHostToDevice, st));
+        HIPOK(hipStreamSynchronize(st));
+      }
     }
     if (e->hint[3]) return fail(e, e->hint[3], "device-side error: a vehicle sits on its target during decide (start == goal is not supported)");
-    e->C.agent_steps += e->n_sched_vehicles;
+    e->C.agent_steps += sched_vehicles_at_shuffle;
     const int deaths = e->hint[1];
     if (deaths > 0) {
       int na = 0, ns = 0;
-      int rc = compact(e, 0, nA, &na); if (rc) return rc;
-      rc = compact(e, 1, nS, &ns); if (rc) return rc;
+      int rc = compact(e, 0, e->n_active, &na); if (rc) return rc;   // spawns of this tick are part of the lists by now
+      rc = compact(e, 1, e->n_sched, &ns); if (rc) return rc;
       e->n_active = na; e->n_sched = ns; e->n_sched_vehicles -= deaths;
       if (e->clock_slot >= 0 && e->mixed_order) {
         // the clock never dies, but dead vehicles scheduled before it shift its slot: find it again
@@ -1558,7 +1655,7 @@ int tick(E* e) {
     }
   }
   host_prof(e, PH_MOVE_WALL, now_ms() - t_move0, nS);
-  if (e->clock_slot >= 0) e->C.elapsed += P.time_per_step_seconds;
+  if (e->clock_slot >= 0 && !e->gen.armed) e->C.elapsed += P.time_per_step_seconds;  // an armed generator did it in its step
   e->C.step_count++;
   if (e->prof) { HIPOK(hipStreamSynchronize(st)); prof_collect(e); }
   return TS_OK;
@@ -1779,6 +1876,43 @@ int ts_schedule_add(ts_handle e, int32_t kind, int32_t count) {
   }
   if (kind == TS_AGENT_CLOCK) e->clock_slot = e->n_sched;
   e->n_sched += count;
+  return TS_OK;
+}
+
+int ts_set_traffic_generator(ts_handle e, const TsTrafficTables* t) {
+  if (!e || !t || t->n_blocks < 0 || t->n_zones < 0 || t->n_zones > 8) return TS_E_INVALID;
+  if (!e->rng_global.seeded()) return fail(e, TS_E_STATE, "seed the global stream before constructing the traffic generator");
+  auto& G = e->gen;
+  G.T = *t;
+  const int W = e->W, H = e->H;
+  auto cellxy = [&](const int32_t* xy, int i, int& out) {
+    int x = xy[2 * i], y = xy[2 * i + 1];
+    if (x < 0 || x >= W || y < 0 || y >= H) return false;
+    out = y * W + x;
+    return true;
+  };
+  G.blk_type.assign(t->blk_type, t->blk_type + t->n_blocks);
+  G.blk_entr.assign(t->n_blocks, {});
+  for (int b = 0; b < t->n_blocks; b++) {
+    for (int k = t->blk_entr_off[b]; k < t->blk_entr_off[b + 1]; k++) {
+      int c;
+      if (!cellxy(t->blk_entr_xy, k, c)) return fail(e, TS_E_INVALID, "block entrance out of bounds");
+      G.blk_entr[b].push_back(c);
+    }
+    if (G.blk_entr[b].empty())
+      return fail(e, TS_E_UNSUPPORTED, "a city block without entrances (random.choice([]) raises in the reference)");
+  }
+  G.hw_in.clear(); G.hw_out.clear();
+  for (int k = 0; k < t->n_highway_entrances; k++) { int c; if (!cellxy(t->highway_entrances_xy, k, c)) return TS_E_INVALID; G.hw_in.push_back(c); }
+  for (int k = 0; k < t->n_highway_exits; k++) { int c; if (!cellxy(t->highway_exits_xy, k, c)) return TS_E_INVALID; G.hw_out.push_back(c); }
+  if ((G.hw_in.empty() || G.hw_out.empty()) && t->passing_population_per_day > 0)
+    return fail(e, TS_E_UNSUPPORTED, "through traffic needs highway entrances and exits");
+  for (int z = 0; z < t->n_zones; z++) if (t->zones[z].n_internal < 0 || t->zones[z].n_internal > 8) return TS_E_INVALID;
+  G.pending.clear();
+  G.current_day = 0;
+  G.armed = true;
+  generate_day(e, 0);
+  e->words_uploaded = e->rng_global.pos();
   return TS_OK;
 }
 
