@@ -109,7 +109,13 @@ typedef struct TsParams {
   int32_t eager_density;                             /* 1: recompute density_map every tick like
                                                         city_model.py:1853; 0: only when a soft A*
                                                         needs it (results are identical) */
-  int32_t _pad1;
+  /* rain clouds (config.py:262-271), used once a TS_AGENT_RAIN_MANAGER is scheduled */
+  int32_t rain_radius_min;                           /* RAIN_RADIUS_MIN = 50 */
+  int32_t rain_radius_max;                           /* RAIN_RADIUS_MAX = 100 */
+  int32_t rain_occurrences_max;                      /* RAIN_OCCURRENCES_MAX = 3 */
+  int32_t rain_cooldown;                             /* RAIN_COOLDOWN = 86400 (seconds; dead code in the reference) */
+  int32_t rain_spawn_offset;                         /* RAIN_SPAWN_OFFSET = 10 */
+  double rain_spawn_chance;                          /* RAIN_SPAWN_CHANCE = 0.1 */
 } TsParams;
 
 /* Static maps produced by world-gen (`_build_simple_maps`, city_model.py:2151-2199). */
@@ -160,7 +166,9 @@ typedef struct TsLightTables {
  * ALL scheduled agents each tick. */
 enum {
   TS_AGENT_LIGHT_GROUP = 0, /* next IntersectionLightGroup, in table order */
-  TS_AGENT_NOOP = 1,        /* CityBlock / RainManager with rain off: occupies a shuffle slot only */
+  TS_AGENT_NOOP = 1,        /* CityBlock: occupies a shuffle slot only */
+  TS_AGENT_RAIN_MANAGER = 2,/* RainManager (rain.py:86-184): spawns RainAgents (each a schedule entry of its own,
+                               added and removed by the engine) and writes rain_map at its place in the order */
   TS_AGENT_CLOCK = 3        /* DynamicTrafficAgent with empty schedule: elapsed += dt (dynamic_traffic_generator.py:153-155) */
 };
 

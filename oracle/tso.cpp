@@ -179,6 +179,14 @@ struct Generator {
   int current_day = 0;
 };
 
+struct Rain {     // RainAgent (rain.py:18-84)
+  double x, y, dx, dy;
+  int radius;
+  std::vector<int> covered;   // covered_cells as of its last step
+  bool alive = true;
+  int sched_idx = -1;
+};
+
 struct SchedEntry {
   int kind;  // TS_AGENT_* or 100 = vehicle
   int ref;
@@ -209,6 +217,10 @@ struct ts_engine {
   TsCounters C;
   std::unordered_map<uint64_t, std::vector<int>> path_cache;  // city._path_cache
   Generator gen;
+  std::vector<Rain> rains_all;     // every RainAgent ever created
+  std::vector<int> rains;          // city_model.rains (indices, list order)
+  std::vector<int> prev_raining;   // RainManager._prev_raining
+  int rain_counter = 0, rain_cooldown_left = 0;
   std::string err;
   // A* scratch (epoch-stamped so the O(N) init of astar_numba.py:119-122 is not repeated)
   std::vector<int> a_dist, a_came, a_epoch;
@@ -894,6 +906,94 @@ void group_step(E* e, int gi) {  // IntersectionLightGroup.step (396-423)
   g.pending_phase = -1;
 }
 
+// ------------------------------ rain (rain.py) ---------------------------------------------------
+// math.hypot of CPython 3.10 (Modules/mathmodule.c vector_norm: Veltkamp splitting + Neumaier sums + one
+// Newton correction); libm's hypot may differ in the last bit.  Checked against the interpreter on 3e5 inputs.
+double py_hypot(double a, double b) {
+  double vec[2] = {std::fabs(a), std::fabs(b)};
+  double max = vec[0] > vec[1] ? vec[0] : vec[1];
+  if (max == 0.0) return 0.0;
+  const double T27 = 134217729.0;
+  double x, scale, oldcsum, csum = 1.0, frac1 = 0.0, frac2 = 0.0, frac3 = 0.0, t, hi, lo, h;
+  int max_e;
+  std::frexp(max, &max_e);
+  scale = std::ldexp(1.0, -max_e);
+  for (int i = 0; i < 2; i++) {
+    x = vec[i]; x *= scale;
+    t = x * T27; hi = t - (t - x); lo = x - hi;
+    x = hi * hi; oldcsum = csum; csum += x; frac1 += (oldcsum - csum) + x;
+    x = 2.0 * hi * lo; oldcsum = csum; csum += x; frac2 += (oldcsum - csum) + x;
+    frac3 += lo * lo;
+  }
+  h = std::sqrt(csum - 1.0 + (frac1 + frac2 + frac3));
+  x = h; t = x * T27; hi = t - (t - x); lo = x - hi;
+  x = -hi * hi; oldcsum = csum; csum += x; frac1 += (oldcsum - csum) + x;
+  x = -2.0 * hi * lo; oldcsum = csum; csum += x; frac2 += (oldcsum - csum) + x;
+  x = -lo * lo; oldcsum = csum; csum += x; frac3 += (oldcsum - csum) + x;
+  x = csum - 1.0 + (frac1 + frac2 + frac3);
+  return (h + x / (2.0 * h)) / scale;
+}
+
+// RainManager.add_random_rain (rain.py:100-148) + RainAgent.__init__ (24-57)
+void add_random_rain(E* e) {
+  const double w = e->W, h = e->H, off = e->P.rain_spawn_offset;
+  const int edge = (int)e->rng_global.randbelow(4);  // random.choice(['N', 'S', 'E', 'W'])
+  double x0, y0, xt, yt;
+  int corner;  // 0 NW, 1 NE, 2 SW, 3 SE
+  if (edge == 0) { x0 = 0.0 + (w - 0.0) * e->rng_global.random(); y0 = h - off; corner = e->rng_global.randbelow(2) ? 3 : 2; }
+  else if (edge == 1) { x0 = 0.0 + (w - 0.0) * e->rng_global.random(); y0 = off; corner = e->rng_global.randbelow(2) ? 1 : 0; }
+  else if (edge == 2) { x0 = w - off; y0 = 0.0 + (h - 0.0) * e->rng_global.random(); corner = e->rng_global.randbelow(2) ? 2 : 0; }
+  else { x0 = off; y0 = 0.0 + (h - 0.0) * e->rng_global.random(); corner = e->rng_global.randbelow(2) ? 3 : 1; }
+  if (corner == 0) { xt = 0; yt = h; } else if (corner == 1) { xt = w; yt = h; } else if (corner == 2) { xt = 0; yt = 0; } else { xt = w; yt = 0; }
+  double dx = xt - x0, dy = yt - y0;
+  double length = py_hypot(dx, dy);
+  if (length == 0.0) length = 1.0;
+  dx /= length; dy /= length;
+  Rain r;
+  r.x = x0; r.y = y0;
+  double l2 = py_hypot(dx, dy);
+  if (l2 == 0.0) l2 = 1.0;
+  r.dx = dx / l2; r.dy = dy / l2;
+  r.radius = e->rng_global.randint(e->P.rain_radius_min, e->P.rain_radius_max);
+  r.sched_idx = (int)e->sched.size();
+  e->sched.push_back(SchedEntry{5, (int)e->rains_all.size(), true});
+  e->rains.push_back((int)e->rains_all.size());
+  e->rains_all.push_back(r);
+  e->rain_counter++;
+}
+
+void rain_manager_step(E* e) {  // RainManager.step (rain.py:156-184)
+  for (int c : e->prev_raining) e->rain[c] = 0;
+  if (e->rain_cooldown_left > 0) e->rain_cooldown_left--;
+  if ((int)e->rains.size() < e->P.rain_occurrences_max && e->rain_cooldown_left == 0 &&
+      e->rng_global.random() < e->P.rain_spawn_chance)
+    add_random_rain(e);
+  e->prev_raining.clear();
+  for (int ri : e->rains)
+    for (int c : e->rains_all[ri].covered) { e->rain[c] = 1; e->prev_raining.push_back(c); }
+}
+
+void rain_agent_step(E* e, int ri) {  // RainAgent.step (rain.py:60-84)
+  Rain& r = e->rains_all[ri];
+  r.x += r.dx; r.y += r.dy;
+  r.covered.clear();
+  const int cx = (int)r.x, cy = (int)r.y, R = r.radius;  // int(): truncation toward zero
+  for (int ox = -R; ox <= R; ox++)
+    for (int oy = -R; oy <= R; oy++) {
+      if (ox * ox + oy * oy > R * R) continue;
+      int xi = cx + ox, yi = cy + oy;
+      if (xi < 0 || xi >= e->W || yi < 0 || yi >= e->H) continue;
+      r.covered.push_back(yi * e->W + xi);
+    }
+  if (r.x < -R || r.x > e->W + R || r.y < -R || r.y > e->H + R) {
+    // manager.on_rain_exit runs while the cloud is still in city_model.rains, so `not rains` is never true and
+    // the cooldown never starts (rain.py:150-154, 79-84)
+    for (size_t k = 0; k < e->rains.size(); k++) if (e->rains[k] == ri) { e->rains.erase(e->rains.begin() + k); break; }
+    e->sched[r.sched_idx].alive = false;
+    r.alive = false;
+  }
+}
+
 // ------------------------------ traffic generator ----------------------------------------------
 extern "C" int tso_add_vehicles(ts_handle e, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
                                 const int32_t* population_type, const int32_t* path_off, const int32_t* path_xy);
@@ -992,6 +1092,7 @@ void tick(E* e) {
       for (size_t i = 0; i < e->sched.size(); i++) {
         if (e->sched[i].alive) {
           if (e->sched[i].kind == 100) e->veh_sched[e->sched[i].ref] = (int)w;
+          if (e->sched[i].kind == 5) e->rains_all[e->sched[i].ref].sched_idx = (int)w;
           e->sched[w++] = e->sched[i];
         }
       }
@@ -1009,6 +1110,8 @@ void tick(E* e) {
     switch (se.kind) {
       case 100: vehicle_step(e, se.ref); break;
       case TS_AGENT_LIGHT_GROUP: group_step(e, se.ref); break;
+      case TS_AGENT_RAIN_MANAGER: rain_manager_step(e); break;
+      case 5: rain_agent_step(e, se.ref); break;
       case TS_AGENT_CLOCK:
         if (e->gen.armed) generator_step(e);
         else e->C.elapsed += e->P.time_per_step_seconds;
@@ -1056,6 +1159,8 @@ void tso_default_params(TsParams* p) {
   p->transition_duration_enabled = 0; p->transition_clearance_enabled = 1; p->all_red_duration = 2;
   p->green_duration = 20; p->qa_min_green = 5; p->qa_max_green = 30; p->qa_gap = 3;
   p->enable_traffic = 1; p->time_per_step_seconds = 6; p->eager_density = 0;
+  p->rain_radius_min = 50; p->rain_radius_max = 100; p->rain_occurrences_max = 3; p->rain_cooldown = 86400;
+  p->rain_spawn_offset = 10; p->rain_spawn_chance = 0.1;
 }
 
 int tso_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
@@ -1142,7 +1247,7 @@ int tso_schedule_add(ts_handle e, int32_t kind, int32_t count) {
     if (kind == TS_AGENT_LIGHT_GROUP) {
       if (e->groups_scheduled >= (int)e->groups.size()) return fail(e, TS_E_INVALID, "more group slots than groups");
       se.ref = e->groups_scheduled++;
-    } else if (kind != TS_AGENT_NOOP && kind != TS_AGENT_CLOCK) return fail(e, TS_E_INVALID, "bad agent kind");
+    } else if (kind != TS_AGENT_NOOP && kind != TS_AGENT_CLOCK && kind != TS_AGENT_RAIN_MANAGER) return fail(e, TS_E_INVALID, "bad agent kind");
     e->sched.push_back(se);
   }
   return TS_OK;

@@ -82,6 +82,11 @@ SCENARIOS = {
     "dta_96_s13": dict(size=96, seed=13, vehicles=40, ticks=160,
                        defaults={"RAIN_ENABLED": False, "TOTAL_SERVICE_VEHICLES_FOOD": 0, "TOTAL_SERVICE_VEHICLES_WASTE": 0,
                                  "INTERNAL_POPULATION_TRAFFIC_PER_DAY": 60000, "PASSING_POPULATION_TRAFFIC_PER_DAY": 20000}),
+    # "next" row 4: rain clouds (RainManager / RainAgent) on a closed population
+    "rain_96_s14": dict(size=96, seed=14, vehicles=150, ticks=220,
+                        defaults={"INTERNAL_POPULATION_TRAFFIC_PER_DAY": 0, "PASSING_POPULATION_TRAFFIC_PER_DAY": 0,
+                                  "TOTAL_SERVICE_VEHICLES_FOOD": 0, "TOTAL_SERVICE_VEHICLES_WASTE": 0, **GATED,
+                                  "RAIN_RADIUS_MIN": 10, "RAIN_RADIUS_MAX": 30, "RAIN_SPAWN_CHANCE": 0.2}),
     # config 1: everything on (rain, traffic generator, service vehicles) - "next" rows
     "config1_64_s11": dict(size=64, seed=11, vehicles=50, ticks=100, defaults={}),
 }
@@ -354,7 +359,7 @@ def run_scenario(name):
     VehicleAgent.__init__ = init
 
     T = spec["ticks"]
-    occ_t, stop_t, stuck_t = [], [], []
+    occ_t, stop_t, stuck_t, rain_t, rain_rows = [], [], [], [], []
     veh_rows, veh_off = [], [0]
     grp_rows = []
     cnt_rows = []
@@ -370,6 +375,10 @@ def run_scenario(name):
         occ_t.append(np.packbits(m.occupancy_map.astype(np.uint8).ravel()))
         stop_t.append(np.packbits(m.stop_map.astype(np.uint8).ravel()))
         stuck_t.append(np.packbits(m.stuck_map.astype(np.uint8).ravel()))
+        rain_t.append(np.packbits((m.rain_map > 0).astype(np.uint8).ravel()))
+        rm = getattr(m, "rain_manager", None)
+        rain_rows.append([len(m.rains), rm.counter if rm else 0, rm.cooldown if rm else 0,
+                          sum(r.radius for r in m.rains), int(sum(int(r.x) + int(r.y) for r in m.rains))])
         for v in m.active_vehicle_agents:
             veh_rows.append(veh_row(v))
         veh_off.append(len(veh_rows))
@@ -386,6 +395,12 @@ def run_scenario(name):
     out["occ_t"] = np.stack(occ_t)
     out["stop_t"] = np.stack(stop_t)
     out["stuck_t"] = np.stack(stuck_t)
+    out["rain_t"] = np.stack(rain_t)
+    out["rain_rows"] = np.asarray(rain_rows, dtype=np.int64)
+    out["rain_params"] = np.asarray(json.dumps(dict(
+        enabled=bool(Defaults.RAIN_ENABLED), radius_min=int(Defaults.RAIN_RADIUS_MIN), radius_max=int(Defaults.RAIN_RADIUS_MAX),
+        occurrences_max=int(Defaults.RAIN_OCCURRENCES_MAX), cooldown=int(Defaults.RAIN_COOLDOWN),
+        spawn_chance=float(Defaults.RAIN_SPAWN_CHANCE), spawn_offset=int(Defaults.RAIN_SPAWN_OFFSET))))
     out["veh_rows"] = np.asarray(veh_rows, dtype=np.int64).reshape(-1, len(VEH_FIELDS)).astype(np.int32)
     out["veh_off"] = np.asarray(veh_off, dtype=np.int32)
     out["grp_rows"] = np.asarray(grp_rows, dtype=np.int32).reshape(T, len(m.intersection_light_groups), len(GRP_FIELDS))

@@ -22,6 +22,7 @@ def trace_path(name):
 
 
 DTA_TRACES = ["dta_64_s12", "dta_96_s13"]
+RAIN_TRACES = ["rain_96_s14"]
 
 
 def setup_from_trace(api, tr, explicit_paths=False):
@@ -83,6 +84,8 @@ def replay_and_compare(api, tr, ticks=None, check_rng=True, check_counters=True)
             raise AssertionError(f"{ctx}: occupancy differs at (x,y)={list(zip(xs[:5], ys[:5]))}")
         assert np.array_equal(api.map(capi.MAP_STOP), _unpack(tr["stop_t"][t], H, W)), f"{ctx}: stop_map"
         assert np.array_equal(api.map(capi.MAP_STUCK), _unpack(tr["stuck_t"][t], H, W)), f"{ctx}: stuck_map"
+        if "rain_t" in tr:
+            assert np.array_equal(api.map(capi.MAP_RAIN), _unpack(tr["rain_t"][t], H, W)), f"{ctx}: rain_map"
         want = tr["veh_rows"][tr["veh_off"][t]:tr["veh_off"][t + 1]]
         got = api.vehicles()
         assert len(got) == len(want), f"{ctx}: live vehicles {len(got)} != {len(want)}"

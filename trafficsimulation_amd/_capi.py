@@ -19,7 +19,7 @@ LIGHT_ALGORITHMS = {
     "DISABLED": 0, "FIXED_TIME": 1, "QUEUE_ACTUATED": 2, "PRESSURE_CONTROL": 3,
     "NEIGHBOR_PRESSURE_CONTROL": 4, "NEIGHBOR_GREEN_WAVE": 5,
 }
-AGENT_LIGHT_GROUP, AGENT_NOOP, AGENT_CLOCK = 0, 1, 3
+AGENT_LIGHT_GROUP, AGENT_NOOP, AGENT_RAIN_MANAGER, AGENT_CLOCK = 0, 1, 2, 3
 MAP_OCCUPANCY, MAP_STOP, MAP_STUCK, MAP_RAIN = 0, 1, 2, 3
 RNG_GLOBAL, RNG_SCHEDULER = 0, 1
 POP = {"undefined": 0, "internal": 1, "through": 2}
@@ -55,7 +55,9 @@ class TsParams(C.Structure):
         ("transition_clearance_enabled", C.c_int32), ("all_red_duration", C.c_int32),
         ("green_duration", C.c_int32), ("qa_min_green", C.c_int32), ("qa_max_green", C.c_int32),
         ("qa_gap", C.c_int32), ("enable_traffic", C.c_int32), ("time_per_step_seconds", C.c_int32),
-        ("eager_density", C.c_int32), ("_pad1", C.c_int32),
+        ("eager_density", C.c_int32), ("rain_radius_min", C.c_int32), ("rain_radius_max", C.c_int32),
+        ("rain_occurrences_max", C.c_int32), ("rain_cooldown", C.c_int32), ("rain_spawn_offset", C.c_int32),
+        ("rain_spawn_chance", C.c_double),
     ]
 
 
@@ -149,6 +151,9 @@ DEFAULTS_TO_PARAMS = {
     "TRAFFIC_LIGHT_QUEUE_ACTUATED_MIN_GREEN": "qa_min_green",
     "TRAFFIC_LIGHT_QUEUE_ACTUATED_MAX_GREEN": "qa_max_green", "TRAFFIC_LIGHT_QUEUE_ACTUATED_GAP": "qa_gap",
     "ENABLE_TRAFFIC": "enable_traffic", "TIME_PER_STEP_IN_SECONDS": "time_per_step_seconds",
+    "RAIN_RADIUS_MIN": "rain_radius_min", "RAIN_RADIUS_MAX": "rain_radius_max",
+    "RAIN_OCCURRENCES_MAX": "rain_occurrences_max", "RAIN_COOLDOWN": "rain_cooldown",
+    "RAIN_SPAWN_OFFSET": "rain_spawn_offset", "RAIN_SPAWN_CHANCE": "rain_spawn_chance",
 }
 
 

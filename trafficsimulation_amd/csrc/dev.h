@@ -13,7 +13,7 @@ constexpr uint16_t VF_EARLY = TS_F_EARLY_EXIT, VF_STUCK = TS_F_STUCK, VF_PARKED 
                    VF_COLL = TS_F_COLLISION, VF_MALF = TS_F_MALFUNCTION, VF_OVER = TS_F_OVERTAKING,
                    VF_DETOUR = TS_F_DETOUR, VF_BLOCKED = TS_F_BLOCKED, VF_HASPREV = TS_F_HAS_PREV,
                    VF_KEEP = 512 /* remove_on_arrival == False */, VF_ALIVE = 1024;
-constexpr int8_t K_VEHICLE = 100, K_DEAD = -1;
+constexpr int8_t K_VEHICLE = 100, K_DEAD = -1, K_RAIN = 5;  // K_RAIN: a RainAgent's schedule entry
 constexpr uint32_t RANK_BITS = 22, RANK_MASK = (1u << RANK_BITS) - 1, EPOCHS = 1u << (32 - RANK_BITS);
 constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
 
@@ -67,6 +67,7 @@ struct Dev {
   int32_t* active;    // active_vehicle_agents (vehicle ids, -1 = removed this tick)
   int8_t* sched_kind;
   int32_t* sched_ref;
+  int32_t* hslot;     // schedule slot of every host-side agent (rain manager, rain clouds), kept by compaction
   uint32_t* rank;     // per schedule slot
   uint8_t* resolved;  // per schedule slot, this move phase
   // light groups (CSR tables + state)

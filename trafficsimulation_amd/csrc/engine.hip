@@ -540,6 +540,7 @@ __global__ void k_compact_scatter(Dev d, int n, int which, const int* block_off,
         out_kind[dst] = k; out_ref[dst] = ref;
         if (k == K_VEHICLE) d.sched_slot[ref] = dst;
         else if (k == TS_AGENT_LIGHT_GROUP) d.g_slot[ref] = dst;
+        else if (k == TS_AGENT_RAIN_MANAGER || k == K_RAIN) d.hslot[ref] = dst;
       }
     }
     __syncthreads();
@@ -656,6 +657,21 @@ __global__ void k_density_pass1(const float* t_occ, const float* t_road, int W, 
   const float area = (float)((2 * r + 1) * (2 * r + 1));
   float v0 = (float)(s0 / size) * area, v1 = (float)(s1 / size) * area;
   density[i] = v1 > 0.f ? __fdiv_rn(v0, v1) : 0.f;
+}
+
+// rain_map = union of the clouds' discs as RainManager.step saw them (rain.py:156-184): a cell is covered by a
+// cloud when (x - cx)^2 + (y - cy)^2 <= r^2 for the cloud's integer centre at its last step
+struct RainDiscs { int n; int cx[16], cy[16], r[16]; };
+__global__ void k_rain_map(int8_t* rain, int W, int H, RainDiscs D) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= W * H) return;
+  const int x = i % W, y = i / W;
+  int8_t v = 0;
+  for (int k = 0; k < D.n; k++) {
+    const int dx = x - D.cx[k], dy = y - D.cy[k];
+    if (dx * dx + dy * dy <= D.r[k] * D.r[k]) v = 1;
+  }
+  rain[i] = v;
 }
 
 // rank[slot] = position of the slot in the shuffled key order
@@ -839,6 +855,14 @@ struct ts_engine {
   TsCounters C;
   std::vector<uint32_t> perm, shuffle_j;
   int32_t* pend_list[2] = {nullptr, nullptr};
+  // RainManager / RainAgent (host side, rain.py): clouds are host agents with a schedule entry of their own
+  struct Rain { double x, y, dx, dy; int radius; bool stepped = false; bool alive = true; int cx = 0, cy = 0; };
+  std::vector<Rain> rains_all;   // indexed by host-agent id - 1 (id 0 is the manager)
+  std::vector<int> rains;        // city_model.rains: ids of live clouds in list order
+  bool rain_manager = false;
+  int rain_counter = 0, rain_cooldown_left = 0;
+  int n_host_agents = 0;         // manager + clouds ever created (hslot entries)
+  int cap_hslot = 0;
   // DynamicTrafficAgent (host side): trip schedule + mid-tick spawning behind the clock agent's schedule slot
   struct Trip { int origin, dest; double depart; int kind; };
   struct Generator {
@@ -1318,6 +1342,122 @@ void shuffle_wait(E* e) {
   e->sh_cv.wait(lk, [e]() { return e->sh_done; });
 }
 
+// a host-side agent (rain manager = id 0, rain clouds = ids 1..) gets a row in the device table of schedule slots
+int host_agent_register(E* e, int slot) {
+  const int hid = e->n_host_agents;
+  if (hid + 1 > e->cap_hslot) {
+    int nc = std::max(64, e->cap_hslot * 2);
+    int rc = regrow(e, &e->d.hslot, (size_t)e->n_host_agents, (size_t)nc);
+    if (rc) return rc;
+    e->cap_hslot = nc;
+  }
+  HIPOK(hipMemcpy(e->d.hslot + hid, &slot, 4, hipMemcpyHostToDevice));
+  e->n_host_agents++;
+  return TS_OK;
+}
+
+// math.hypot of CPython 3.10 (Modules/mathmodule.c vector_norm); libm's hypot can differ in the last bit
+double py_hypot(double a, double b) {
+  double vec[2] = {std::fabs(a), std::fabs(b)};
+  double max = vec[0] > vec[1] ? vec[0] : vec[1];
+  if (max == 0.0) return 0.0;
+  const double T27 = 134217729.0;
+  double x, scale, oldcsum, csum = 1.0, frac1 = 0.0, frac2 = 0.0, frac3 = 0.0, t, hi, lo, h;
+  int max_e;
+  std::frexp(max, &max_e);
+  scale = std::ldexp(1.0, -max_e);
+  for (int i = 0; i < 2; i++) {
+    x = vec[i]; x *= scale;
+    t = x * T27; hi = t - (t - x); lo = x - hi;
+    x = hi * hi; oldcsum = csum; csum += x; frac1 += (oldcsum - csum) + x;
+    x = 2.0 * hi * lo; oldcsum = csum; csum += x; frac2 += (oldcsum - csum) + x;
+    frac3 += lo * lo;
+  }
+  h = std::sqrt(csum - 1.0 + (frac1 + frac2 + frac3));
+  x = h; t = x * T27; hi = t - (t - x); lo = x - hi;
+  x = -hi * hi; oldcsum = csum; csum += x; frac1 += (oldcsum - csum) + x;
+  x = -2.0 * hi * lo; oldcsum = csum; csum += x; frac2 += (oldcsum - csum) + x;
+  x = -lo * lo; oldcsum = csum; csum += x; frac3 += (oldcsum - csum) + x;
+  x = csum - 1.0 + (frac1 + frac2 + frac3);
+  return (h + x / (2.0 * h)) / scale;
+}
+
+// RainManager.add_random_rain (rain.py:100-148) + RainAgent.__init__ (24-57) + schedule.add(rain)
+int rain_add_random(E* e) {
+  MTPipe& r = e->rng_global;
+  const double w = e->W, h = e->H, off = e->P.rain_spawn_offset;
+  const int edge = (int)r.randbelow(4);  // random.choice(['N', 'S', 'E', 'W'])
+  double x0, y0, xt, yt;
+  int corner;  // 0 NW, 1 NE, 2 SW, 3 SE
+  if (edge == 0) { x0 = 0.0 + (w - 0.0) * r.random(); y0 = h - off; corner = r.randbelow(2) ? 3 : 2; }
+  else if (edge == 1) { x0 = 0.0 + (w - 0.0) * r.random(); y0 = off; corner = r.randbelow(2) ? 1 : 0; }
+  else if (edge == 2) { x0 = w - off; y0 = 0.0 + (h - 0.0) * r.random(); corner = r.randbelow(2) ? 2 : 0; }
+  else { x0 = off; y0 = 0.0 + (h - 0.0) * r.random(); corner = r.randbelow(2) ? 3 : 1; }
+  if (corner == 0) { xt = 0; yt = h; } else if (corner == 1) { xt = w; yt = h; } else if (corner == 2) { xt = 0; yt = 0; } else { xt = w; yt = 0; }
+  double dx = xt - x0, dy = yt - y0;
+  double length = py_hypot(dx, dy);
+  if (length == 0.0) length = 1.0;
+  dx /= length; dy /= length;
+  ts_engine::Rain c;
+  c.x = x0; c.y = y0;
+  double l2 = py_hypot(dx, dy);
+  if (l2 == 0.0) l2 = 1.0;
+  c.dx = dx / l2; c.dy = dy / l2;
+  c.radius = r.randint(e->P.rain_radius_min, e->P.rain_radius_max);
+  // schedule.add(rain): a new entry at the end of the schedule (it does not step in the tick that created it)
+  if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
+  int rc = ensure_vehicle_capacity(e, e->cap_v, e->n_sched + 1);
+  if (rc) return rc;
+  const int hid = e->n_host_agents;
+  rc = host_agent_register(e, e->n_sched);
+  if (rc) return rc;
+  const int8_t kind = K_RAIN;
+  HIPOK(hipMemcpy(e->d.sched_kind + e->n_sched, &kind, 1, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(e->d.sched_ref + e->n_sched, &hid, 4, hipMemcpyHostToDevice));
+  e->n_sched++;
+  e->mixed_order = true;
+  e->rains.push_back(hid);
+  e->rains_all.resize((size_t)hid);   // ids are 1-based behind the manager
+  e->rains_all[(size_t)hid - 1] = c;
+  e->rain_counter++;
+  return TS_OK;
+}
+
+// RainManager.step (rain.py:156-184); the discs it saw are what rain_map becomes
+int rain_manager_step(E* e, RainDiscs& discs) {
+  if (e->rain_cooldown_left > 0) e->rain_cooldown_left--;
+  if ((int)e->rains.size() < e->P.rain_occurrences_max && e->rain_cooldown_left == 0 &&
+      e->rng_global.random() < e->P.rain_spawn_chance) {
+    int rc = rain_add_random(e);
+    if (rc) return rc;
+  }
+  discs.n = 0;
+  for (int hid : e->rains) {
+    const auto& c = e->rains_all[(size_t)hid - 1];
+    if (!c.stepped) continue;   // covered_cells is empty until the cloud's first step
+    if (discs.n >= 16) return fail(e, TS_E_CAPACITY, "more than 16 rain clouds");
+    discs.cx[discs.n] = c.cx; discs.cy[discs.n] = c.cy; discs.r[discs.n] = c.radius; discs.n++;
+  }
+  return TS_OK;
+}
+
+// RainAgent.step (rain.py:60-84).  Returns 1 if the cloud left the map (schedule.remove(self)).
+int rain_agent_step(E* e, int hid) {
+  auto& c = e->rains_all[(size_t)hid - 1];
+  c.x += c.dx; c.y += c.dy;
+  c.cx = (int)c.x; c.cy = (int)c.y;   // int(): truncation toward zero
+  c.stepped = true;
+  const int R = c.radius;
+  if (c.x < -R || c.x > e->W + R || c.y < -R || c.y > e->H + R) {
+    // on_rain_exit runs while the cloud is still in city_model.rains: `not rains` is never true there, so the
+    // cooldown never starts (rain.py:150-154)
+    for (size_t k = 0; k < e->rains.size(); k++) if (e->rains[k] == hid) { e->rains.erase(e->rains.begin() + k); break; }
+    c.alive = false;
+    return 1;
+  }
+  return 0;
+}
+
 // _generate_day (dynamic_traffic_generator.py:307-396), internal + through trips; service quotas must be 0
 void generate_day(E* e, int day_idx) {
   auto& G = e->gen;
@@ -1593,6 +1733,44 @@ int tick(E* e) {
     // With an armed traffic generator the phase runs in two parts: first every agent ranked before it, then the
     // generator's own step on the host (spawns plan on the maps as they are at that point), then the rest.
     const bool split = e->gen.armed && e->clock_slot >= 0;
+    // Host-side agents (rain manager, rain clouds) step at their ranks too.  They only touch host state and the
+    // global stream, so they need no device synchronisation of their own: the ones ranked before the traffic
+    // generator run now, the others after its step.  Clouds created during this tick do not step.
+    struct HostEv { uint32_t rank; int hid; int slot; };
+    std::vector<HostEv> host_events;
+    RainDiscs discs; discs.n = -1;   // -1: the manager has not stepped in this tick
+    int host_deaths = 0;
+    if (e->rain_manager) {
+      const int nh = e->n_host_agents;
+      std::vector<int32_t> slots(nh);
+      HIPOK(hipMemcpyAsync(slots.data(), d.hslot, (size_t)nh * 4, hipMemcpyDeviceToHost, st));
+      HIPOK(hipStreamSynchronize(st));
+      std::vector<uint32_t> ranks(nh);
+      for (int hdx = 0; hdx < nh; hdx++) {
+        if (hdx > 0 && !e->rains_all[(size_t)hdx - 1].alive) continue;
+        HIPOK(hipMemcpyAsync(&ranks[hdx], d.rank + slots[hdx], 4, hipMemcpyDeviceToHost, st));
+      }
+      HIPOK(hipStreamSynchronize(st));
+      for (int hdx = 0; hdx < nh; hdx++) {
+        if (hdx > 0 && !e->rains_all[(size_t)hdx - 1].alive) continue;
+        host_events.push_back(HostEv{ranks[hdx], hdx, slots[hdx]});
+      }
+      std::sort(host_events.begin(), host_events.end(), [](const HostEv& a, const HostEv& b) { return a.rank < b.rank; });
+    }
+    auto run_host_events = [&](uint32_t lo, uint32_t hi) -> int {   // events with lo <= rank < hi, in rank order
+      for (const HostEv& ev : host_events) {
+        if (ev.rank < lo || ev.rank >= hi) continue;
+        if (ev.hid == 0) { int rc = rain_manager_step(e, discs); if (rc) return rc; }
+        else if (rain_agent_step(e, ev.hid)) {
+          const int8_t dead = K_DEAD;   // schedule.remove(self)
+          HIPOK(hipMemcpyAsync(d.sched_kind + ev.slot, &dead, 1, hipMemcpyHostToDevice, st));
+          HIPOK(hipStreamSynchronize(st));
+          host_deaths++;
+        }
+      }
+      return TS_OK;
+    };
+    { int rc = run_host_events(0, split ? rank_clock : NO_RANK); if (rc) return rc; }
     int done = 0;
     for (int part = split ? 0 : 1; part < 2; part++) {
       const uint32_t rank_limit = part == 0 ? rank_clock : NO_RANK;
@@ -1630,6 +1808,8 @@ int tick(E* e) {
         // the generator's turn: DynamicTrafficAgent.step on the host, then mark its slot as stepped
         int rc = generator_step(e);
         if (rc) return rc;
+        rc = run_host_events(rank_clock + 1, NO_RANK);
+        if (rc) return rc;
         const uint8_t one = 1;
         HIPOK(hipMemcpyAsync(d.resolved + e->clock_slot, &one, 1, hipMemcpyHostToDevice, st));
         done += 1;
@@ -1638,13 +1818,16 @@ int tick(E* e) {
       }
     }
     if (e->hint[3]) return fail(e, e->hint[3], "device-side error: a vehicle sits on its target during decide (start == goal is not supported)");
+    if (discs.n >= 0)   // RainManager.step ran: rain_map is exactly the union of the discs it saw
+      hipLaunchKernelGGL(k_rain_map, dim3(nblk((long long)e->N)), dim3(BLK), 0, st, d.rain, e->W, e->H, discs);
     e->C.agent_steps += sched_vehicles_at_shuffle;
-    const int deaths = e->hint[1];
+    const int vehicle_deaths = e->hint[1];
+    const int deaths = vehicle_deaths + host_deaths;
     if (deaths > 0) {
       int na = 0, ns = 0;
       int rc = compact(e, 0, e->n_active, &na); if (rc) return rc;   // spawns of this tick are part of the lists by now
       rc = compact(e, 1, e->n_sched, &ns); if (rc) return rc;
-      e->n_active = na; e->n_sched = ns; e->n_sched_vehicles -= deaths;
+      e->n_active = na; e->n_sched = ns; e->n_sched_vehicles -= vehicle_deaths;
       if (e->clock_slot >= 0 && e->mixed_order) {
         // the clock never dies, but dead vehicles scheduled before it shift its slot: find it again
         std::vector<int8_t> kinds(ns);
@@ -1686,6 +1869,8 @@ void ts_default_params(TsParams* p) {
   p->transition_duration_enabled = 0; p->transition_clearance_enabled = 1; p->all_red_duration = 2;
   p->green_duration = 20; p->qa_min_green = 5; p->qa_max_green = 30; p->qa_gap = 3;
   p->enable_traffic = 1; p->time_per_step_seconds = 6; p->eager_density = 0;
+  p->rain_radius_min = 50; p->rain_radius_max = 100; p->rain_occurrences_max = 3; p->rain_cooldown = 86400;
+  p->rain_spawn_offset = 10; p->rain_spawn_chance = 0.1;
 }
 
 int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
@@ -1852,8 +2037,10 @@ int ts_set_lights(ts_handle e, const TsLightTables* t) {
 
 int ts_schedule_add(ts_handle e, int32_t kind, int32_t count) {
   if (!e || count < 0) return TS_E_INVALID;
-  if (kind != TS_AGENT_LIGHT_GROUP && kind != TS_AGENT_NOOP && kind != TS_AGENT_CLOCK)
+  if (kind != TS_AGENT_LIGHT_GROUP && kind != TS_AGENT_NOOP && kind != TS_AGENT_CLOCK && kind != TS_AGENT_RAIN_MANAGER)
     return fail(e, TS_E_INVALID, "bad agent kind");
+  if (kind == TS_AGENT_RAIN_MANAGER && (count > 1 || e->rain_manager) && count > 0)
+    return fail(e, TS_E_INVALID, "at most one rain manager");
   if (kind == TS_AGENT_LIGHT_GROUP && e->groups_scheduled + count > e->d.G)
     return fail(e, TS_E_INVALID, "more group slots than groups");
   if (kind == TS_AGENT_CLOCK && (count > 1 || e->clock_slot >= 0) && count > 0)
@@ -1875,6 +2062,11 @@ int ts_schedule_add(ts_handle e, int32_t kind, int32_t count) {
     e->groups_scheduled += count;
   }
   if (kind == TS_AGENT_CLOCK) e->clock_slot = e->n_sched;
+  if (kind == TS_AGENT_RAIN_MANAGER) {   // host agent id 0
+    rc = host_agent_register(e, e->n_sched);
+    if (rc) return rc;
+    e->rain_manager = true;
+  }
   e->n_sched += count;
   return TS_OK;
 }
