@@ -169,7 +169,9 @@ enum {
   TS_AGENT_NOOP = 1,        /* CityBlock: occupies a shuffle slot only */
   TS_AGENT_RAIN_MANAGER = 2,/* RainManager (rain.py:86-184): spawns RainAgents (each a schedule entry of its own,
                                added and removed by the engine) and writes rain_map at its place in the order */
-  TS_AGENT_CLOCK = 3        /* DynamicTrafficAgent with empty schedule: elapsed += dt (dynamic_traffic_generator.py:153-155) */
+  TS_AGENT_CLOCK = 3,       /* DynamicTrafficAgent: elapsed += dt (dynamic_traffic_generator.py:153-155); spawns once
+                               ts_set_traffic_generator armed it */
+  TS_AGENT_CITY_BLOCK = 6   /* next CityBlock in city_blocks order: food / waste bookkeeping (city_block.py:148-150) */
 };
 
 /* DynamicTrafficAgent (dynamic_traffic_generator.py:71-150, 307-430): the daily trip schedule and the mid-tick
@@ -195,6 +197,23 @@ typedef struct TsTrafficTables {
   int32_t start_offset_seconds;         /* SIMULATION_STARTING_TIME_OF_DAY_* in seconds */
   int32_t n_zones;
   TsTrafficZone zones[8];
+  /* service vehicles + CityBlock resources (vehicle_service.py, city_block.py); all zero = not used */
+  int32_t total_service_vehicles_food;  /* TOTAL_SERVICE_VEHICLES_FOOD = 50 */
+  int32_t total_service_vehicles_waste; /* TOTAL_SERVICE_VEHICLES_WASTE = 50 */
+  int32_t service_load_time;            /* SERVICE_VEHICLE_LOAD_TIME = 20 */
+  int32_t gradual_city_block_resources; /* GRADUAL_CITY_BLOCK_RESOURCES = True */
+  int32_t food_consumption_ticks;       /* FOOD_CONSUMPTION_TICKS = 50 */
+  int32_t waste_production_ticks;       /* WASTE_PRODUCTION_TICKS = 100 */
+  int32_t needs_food_type_mask;         /* bit t set: block type t is in CITY_BLOCK_THAT_NEED_FOOD (Market, Leisure) */
+  int32_t produces_waste_type_mask;     /* bit t set: block type t is in CITY_BLOCK_THAT_PRODUCE_WASTE (all five) */
+  double service_max_load_food;         /* SERVICE_VEHICLE_MAX_LOAD_FOOD = 50 */
+  double service_max_load_waste;        /* SERVICE_VEHICLE_MAX_LOAD_WASTE = 250 */
+  double food_capacity_per_cell;        /* FOOD_CAPACITY_PER_CELL = 2 */
+  double waste_capacity_per_cell;       /* WASTE_CAPACITY_PER_CELL = 1.5 */
+  const int32_t* blk_inner_cells;       /* [n_blocks] len(CityBlock._inner_blocks) */
+  const int32_t* blk_service_off;       /* [n_blocks+1] CityBlock.get_service_road_cell's ranked candidates */
+  const int32_t* blk_service_xy;        /*   (city_block.py:152-190: static; ties in CPython set order, so the
+                                             list is an input recorded from the interpreter, not recomputed) */
 } TsTrafficTables;
 
 /* dynamic_traffic_generator.py:102-131 counters that the hot path writes. */
@@ -213,6 +232,7 @@ typedef struct TsCounters {
   int64_t move_rounds;         /* dependency-resolution rounds executed by the move phase */
   int64_t rng_fixups;          /* decide-phase re-scans caused by malfunction/collision events */
   int64_t created_internal, created_through; /* DynamicTrafficAgent.created_* (reset at day rollover) */
+  int64_t created_service_food, created_service_waste, live_service_food, live_service_waste;
 } TsCounters;
 
 /* One row per live vehicle, in `active_vehicle_agents` order (city_model.py:1903). */
@@ -239,6 +259,8 @@ enum {
 enum { TS_MAP_OCCUPANCY = 0, TS_MAP_STOP = 1, TS_MAP_STUCK = 2, TS_MAP_RAIN = 3 };
 enum { TS_RNG_GLOBAL = 0, TS_RNG_SCHEDULER = 1 };
 enum { TS_POP_UNDEFINED = 0, TS_POP_INTERNAL = 1, TS_POP_THROUGH = 2 };
+/* Trip kinds of the traffic generator beyond the two population types */
+enum { TS_TRIP_SERVICE_FOOD = 3, TS_TRIP_SERVICE_WASTE = 4 };
 
 /* config.py defaults. */
 void ts_default_params(TsParams* p);
@@ -302,6 +324,9 @@ int ts_download_vehicles(ts_handle h, int32_t* rows, int32_t cap_rows); /* [n][T
 /* remaining path of the vehicle at position `active_pos`; returns its length (cells). */
 int ts_download_path(ts_handle h, int32_t active_pos, int32_t* xy, int32_t cap_cells);
 int ts_download_groups(ts_handle h, int32_t* rows); /* [G][TS_G_NFIELDS] */
+/* CityBlock.get_food_units() / get_waste_units() per block, city_blocks order (city_block.py:100-101); rows [n][2] */
+int ts_num_blocks(ts_handle h);
+int ts_download_blocks(ts_handle h, double* rows);
 int ts_counters(ts_handle h, TsCounters* out);
 
 /* The pathfinder operator seam: astar(width, height, sx, sy, gx, gy, occupancy_map, stop_map,

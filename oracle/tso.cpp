@@ -149,6 +149,13 @@ struct Vehicle {
   double depart_time = 0.0;
   int steps_traveled = 0;
   bool alive = true;
+  // ServiceVehicleAgent (vehicle_service.py:13-41)
+  int svc_type = 0;        // 0 = plain VehicleAgent, TS_TRIP_SERVICE_FOOD / TS_TRIP_SERVICE_WASTE
+  int svc_phase = 0;       // 0 "to_block", 1 "servicing", 2 "to_exit"
+  int service_ticks = 0;
+  int svc_id = -1;         // index into sv_food_ids / sv_waste_ids
+  int current_block = -1;
+  double max_load = 0.0, current_load = 0.0;
   int next_in_cell = -1;  // MultiGrid cell list (vehicles only, arrival order)
   size_t plen() const { return path.size() - head; }
   bool stranded() const { return is_in_collision || is_in_malfunction; }
@@ -168,8 +175,19 @@ struct Group {
   int ns_pressure = 0, ew_pressure = 0;
 };
 
-struct Trip { int origin, dest; double depart; int kind; };  // kind: TS_POP_INTERNAL / TS_POP_THROUGH
+struct Trip { int origin, dest; double depart; int kind; };  // kind: TS_POP_INTERNAL / TS_POP_THROUGH / TS_TRIP_SERVICE_*
+struct Block {   // CityBlock (city_block.py:39-77)
+  int cells = 0;
+  bool needs_food = false, produces_waste = false;
+  double max_food = 0, max_waste = 0, food = 0, waste = 0;
+  double food_rate = 0, waste_rate = 0, food_rem = 0, waste_rem = 0;
+  int ticks_since_food = 0, ticks_since_waste = 0;
+  std::vector<int> service_cells;   // get_service_road_cell's ranked candidates
+};
 struct Generator {
+  std::vector<Block> blocks;
+  int blocks_scheduled = 0;
+  std::vector<char> sv_live;        // service ids currently in the scheduler: [food ids..., waste ids...]
   bool armed = false;
   TsTrafficTables T;
   std::vector<int> blk_type;
@@ -222,6 +240,8 @@ struct ts_engine {
   std::vector<int> prev_raining;   // RainManager._prev_raining
   int rain_counter = 0, rain_cooldown_left = 0;
   std::string err;
+  int svc_pending_type = 0;   // vehicle_type of the vehicle tso_add_vehicles is placing
+  int fatal = 0;   // an exception the reference would have raised inside model.step()
   // A* scratch (epoch-stamped so the O(N) init of astar_numba.py:119-122 is not repeated)
   std::vector<int> a_dist, a_came, a_epoch;
   int epoch = 0;
@@ -472,8 +492,11 @@ bool tick_stranded(E* e, Vehicle& v) {  // vehicle_base.py:552-565
 
 void remove_vehicle(E* e, int vid);
 
-void on_target_reached(E* e, int vid) {  // vehicle_base.py:755-775
+void start_service(E* e, int vid);
+
+void on_target_reached(E* e, int vid) {  // vehicle_base.py:755-775; vehicle_service.py:54-60
   Vehicle& v = e->veh[vid];
+  if (v.svc_type && v.svc_phase == 0) { start_service(e, vid); return; }
   if (e->P.enable_traffic) {
     double duration = e->C.elapsed - v.depart_time;
     if (v.pop_type == TS_POP_INTERNAL) {
@@ -495,7 +518,12 @@ void remove_vehicle(E* e, int vid) {  // city_model.py:1920-1941
   cell_remove(e, v.pos, vid);
   e->sched[e->veh_sched[vid]].alive = false;
   if (v.pop_type == TS_POP_INTERNAL) e->C.live_internal--;
-  else if (v.pop_type == TS_POP_THROUGH) e->C.live_through--;
+  else if (v.pop_type == TS_POP_THROUGH) {
+    e->C.live_through--;
+    if (v.svc_type == TS_TRIP_SERVICE_FOOD) e->C.live_service_food--;
+    else if (v.svc_type == TS_TRIP_SERVICE_WASTE) e->C.live_service_waste--;
+  }
+  if (v.svc_type) e->gen.sv_live[(v.svc_type == TS_TRIP_SERVICE_FOOD ? 0 : e->gen.T.total_service_vehicles_food) + v.svc_id] = 0;
   v.alive = false; v.pos = -1;
 }
 
@@ -777,9 +805,15 @@ void move_to(E* e, int vid, int new_pos) {
 }
 
 // VehicleAgent.step with PATHFINDING_BATCHING=True (vehicle_base.py:666-685)
+void finish_service(E* e, int vid);
 void vehicle_step(E* e, int vid) {
   Vehicle& v = e->veh[vid];
   e->C.agent_steps++;
+  if (v.svc_type && v.svc_phase == 1) {  // ServiceVehicleAgent.step (vehicle_service.py:43-52)
+    v.service_ticks -= 1;
+    if (v.service_ticks <= 0) finish_service(e, vid);
+    return;
+  }
   if (!v.early_exit) {
     // _execute_movement (733-753)
     for (int step_idx = 0; step_idx < v.max_steps; step_idx++) {
@@ -802,6 +836,119 @@ void vehicle_step(E* e, int vid) {
   }
   if (v.pos == v.target) on_target_reached(e, vid);
   // _despawn_check (695-706): VEHICLE_STUCK_DESPAWN_ENABLED = False (config.py:315); not restated.
+}
+
+
+// ------------------------------ city blocks + service vehicles -------------------------------
+// CityBlock.step (city_block.py:110-150)
+void block_step(E* e, int bi) {
+  if (bi >= (int)e->gen.blocks.size()) return;   // no block tables: nothing observable
+  Block& b = e->gen.blocks[bi];
+  const TsTrafficTables& T = e->gen.T;
+  if (b.needs_food) {
+    if (T.gradual_city_block_resources) {
+      b.food_rem += b.food_rate;
+      if (b.food_rem >= 1.0) {
+        double whole = std::trunc(b.food_rem);   // int(remainder)
+        b.food = std::max(b.food - whole, 0.0);
+        b.food_rem -= whole;
+      }
+    } else if (++b.ticks_since_food >= T.food_consumption_ticks) {
+      b.food = std::max(b.food - (double)b.cells, 0.0);
+      b.ticks_since_food = 0;
+    }
+  }
+  if (b.produces_waste) {
+    if (T.gradual_city_block_resources) {
+      b.waste_rem += b.waste_rate;
+      if (b.waste_rem >= 1.0) {
+        double whole = std::trunc(b.waste_rem);
+        b.waste = std::min(b.waste + whole, b.max_waste);
+        b.waste_rem -= whole;
+      }
+    } else if (++b.ticks_since_waste >= T.waste_production_ticks) {
+      b.waste = std::min(b.waste + (double)b.cells, b.max_waste);
+      b.ticks_since_waste = 0;
+    }
+  }
+}
+
+// CityBlock.get_service_road_cell step 4 (city_block.py:192-202): first ranked cell without a parked vehicle
+int service_road_cell(E* e, int bi) {
+  for (int c : e->gen.blocks[bi].service_cells) {
+    bool parked = false;
+    for (int a = e->cell_head[c]; a >= 0; a = e->veh[a].next_in_cell) if (e->veh[a].is_parked) { parked = true; break; }
+    if (!parked) return c;
+  }
+  return -1;
+}
+
+// ServiceVehicleAgent._start_service (vehicle_service.py:85-104)
+void start_service(E* e, int vid) {
+  Vehicle& v = e->veh[vid];
+  if (!v.is_parked) { v.is_parked = true; e->C.parked++; }
+  Block& b = e->gen.blocks[v.current_block];
+  if (v.svc_type == TS_TRIP_SERVICE_FOOD) {
+    double need = b.max_food - b.food;
+    double amt = std::min(v.current_load, need);
+    b.food = std::min(b.food + amt, b.max_food);
+    v.current_load -= amt;
+  } else {
+    double surplus = b.waste;
+    double cap = v.max_load - v.current_load;
+    double amt = std::min(cap, surplus);
+    b.waste = std::max(b.waste - amt, 0.0);
+    v.current_load += amt;
+  }
+  v.service_ticks = e->gen.T.service_load_time;
+  v.svc_phase = 1;
+}
+
+// ServiceVehicleAgent._finish_service (vehicle_service.py:106-141)
+void finish_service(E* e, int vid) {
+  Vehicle& v = e->veh[vid];
+  Generator& G = e->gen;
+  if (v.is_parked) { v.is_parked = false; e->C.parked--; }
+  bool more = v.svc_type == TS_TRIP_SERVICE_FOOD ? v.current_load > 0 : v.current_load < v.max_load;
+  if (more) {
+    // get_block_most_in_need_of_food / _waste_pickup (city_model.py:2078-2087): stable sorts, first element
+    int next_blk = -1;
+    for (size_t b = 0; b < G.blocks.size(); b++) {
+      const Block& B = G.blocks[b];
+      if (v.svc_type == TS_TRIP_SERVICE_FOOD) {
+        if (B.needs_food && (next_blk < 0 || B.food < G.blocks[next_blk].food)) next_blk = (int)b;
+      } else {
+        if (B.produces_waste && (next_blk < 0 || B.waste > G.blocks[next_blk].waste)) next_blk = (int)b;
+      }
+    }
+    if (next_blk >= 0) {
+      v.current_block = next_blk;
+      int cell = service_road_cell(e, next_blk);
+      if (cell < 0) {  // self.target = None -> _compute_path raises AttributeError
+        e->fatal = TS_E_UNSUPPORTED;
+        e->err = "service vehicle: every service road cell of the next block holds a parked vehicle (the reference raises)";
+        return;
+      }
+      v.target = cell;
+      std::vector<int> p;
+      compute_path(e, vid, true, p);
+      set_path(v, p);
+      v.svc_phase = 0;
+      return;
+    }
+  }
+  const int W = e->W;
+  int best = -1, best_d = 0;
+  for (int c : G.hw_out) {   // min(exits, key=manhattan): first minimum
+    int d = std::abs(c % W - v.pos % W) + std::abs(c / W - v.pos / W);
+    if (best < 0 || d < best_d) { best = c; best_d = d; }
+  }
+  v.target = best;
+  std::vector<int> p;
+  compute_path(e, vid, true, p);
+  set_path(v, p);
+  v.remove_on_arrival = true;
+  v.svc_phase = 2;
 }
 
 // ------------------------------ light groups ---------------------------------------------------
@@ -1001,6 +1148,19 @@ extern "C" int tso_add_vehicles(ts_handle e, int32_t n, const int32_t* start_xy,
 // _generate_day (dynamic_traffic_generator.py:307-396) for internal and through trips
 void generate_day(E* e, int day_idx) {
   Generator& G = e->gen;
+  // compute_quotas (319-331): floors + the largest fractional parts (stable, descending)
+  auto quotas = [&](int total) {
+    const int nz = G.T.n_zones;
+    std::vector<double> fc(nz);
+    std::vector<int> fl(nz), order(nz);
+    long long sum = 0;
+    for (int z = 0; z < nz; z++) { fc[z] = (double)total * G.T.zones[z].through_distribution; fl[z] = (int)std::floor(fc[z]); sum += fl[z]; order[z] = z; }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return fc[a] - std::floor(fc[a]) > fc[b] - std::floor(fc[b]); });
+    long long rem = total - sum;
+    for (long long i = 0; i < rem && i < nz; i++) fl[order[i]] += 1;
+    return fl;
+  };
+  const std::vector<int> food_q = quotas(G.T.total_service_vehicles_food), waste_q = quotas(G.T.total_service_vehicles_waste);
   for (int zi = 0; zi < G.T.n_zones; zi++) {
     const TsTrafficZone& z = G.T.zones[zi];
     const double z0 = (double)((long long)day_idx * 86400 + (long long)z.start_hour * 3600 - G.T.start_offset_seconds);
@@ -1024,8 +1184,20 @@ void generate_day(E* e, int day_idx) {
         G.pending.push_back(Trip{oc, dc, t, TS_POP_INTERNAL});
       }
     }
-    // service quotas are zero here (TOTAL_SERVICE_VEHICLES_* = 0): no draws
+    // service vehicles, uniform per zone (362-376): one entrance draw per trip
+    const int Nf = food_q[zi], Nw = waste_q[zi];
+    for (int j = 1; j <= Nf; j++) {
+      double t = z0 + (double)((long long)j * (long long)span) / (double)(Nf + 1);
+      int sc = G.hw_in[e->rng_global.randbelow((uint32_t)G.hw_in.size())];
+      G.pending.push_back(Trip{sc, -1, t, TS_TRIP_SERVICE_FOOD});
+    }
+    for (int j = 1; j <= Nw; j++) {
+      double t = z0 + (double)((long long)j * (long long)span) / (double)(Nw + 1);
+      int sc = G.hw_in[e->rng_global.randbelow((uint32_t)G.hw_in.size())];
+      G.pending.push_back(Trip{sc, -1, t, TS_TRIP_SERVICE_WASTE});
+    }
     long long thr = (long long)std::nearbyint((double)G.T.passing_population_per_day * z.through_distribution);
+    thr -= Nf + Nw;   // SERVICE_VEHICLES_COUNT_AS_THROUGH defaults to True (90, 381-382)
     if (thr < 0) thr = 0;
     for (long long q = 0; q < thr; q++) {
       double t = z0 + e->rng_global.random() * span;
@@ -1034,6 +1206,52 @@ void generate_day(E* e, int day_idx) {
       G.pending.push_back(Trip{ent, ex, t, TS_POP_THROUGH});
     }
   }
+}
+
+
+// _spawn for service trips (dynamic_traffic_generator.py:419-430) + ServiceVehicleAgent.__init__ (vehicle_service.py:19-41)
+void spawn_service(E* e, const Trip& t) {
+  Generator& G = e->gen;
+  const bool food = t.kind == TS_TRIP_SERVICE_FOOD;
+  if (food) e->C.created_service_food++; else e->C.created_service_waste++;
+  const int pool = food ? G.T.total_service_vehicles_food : G.T.total_service_vehicles_waste;
+  const int id = (int)e->rng_global.randbelow((uint32_t)pool);   // vid = random.choice(pool)
+  // _find_initial_target (62-83): `attempt` is never advanced, so only valid_blocks[0] is ever tried
+  int blk = -1;
+  for (size_t b = 0; b < G.blocks.size(); b++)
+    if (food ? G.blocks[b].needs_food : G.blocks[b].produces_waste) { blk = (int)b; break; }
+  int target, phase;
+  if (blk >= 0) {
+    target = service_road_cell(e, blk);
+    if (target < 0) {
+      e->fatal = TS_E_UNSUPPORTED;
+      e->err = "service vehicle: no free service road cell at its first block (the reference loops forever)";
+      return;
+    }
+    phase = 0;
+  } else {
+    if (G.hw_out.empty()) { e->fatal = TS_E_UNSUPPORTED; e->err = "service vehicle without highway exits (IndexError in the reference)"; return; }
+    target = G.hw_out[0];
+    phase = 2;
+  }
+  char& live = G.sv_live[(food ? 0 : G.T.total_service_vehicles_food) + id];
+  if (live) {   // BaseScheduler.add raises on a unique_id that is already scheduled (Mesa <= 2.1)
+    e->fatal = TS_E_UNSUPPORTED;
+    e->err = "service vehicle id drawn while a vehicle with that id is still live (the scheduler raises in the reference)";
+    return;
+  }
+  int32_t s[2] = {t.origin % e->W, t.origin / e->W}, g[2] = {target % e->W, target / e->W};
+  int32_t pop = TS_POP_THROUGH;
+  e->svc_pending_type = t.kind;
+  tso_add_vehicles(e, 1, s, g, &pop, nullptr, nullptr);
+  e->svc_pending_type = 0;
+  Vehicle& v = e->veh.back();
+  live = 1;
+  v.svc_id = id; v.svc_phase = phase; v.current_block = blk;
+  v.max_load = food ? G.T.service_max_load_food : G.T.service_max_load_waste;
+  v.current_load = food ? v.max_load : 0.0;
+  v.remove_on_arrival = false;
+  v.service_ticks = 0;
 }
 
 // DynamicTrafficAgent.step (dynamic_traffic_generator.py:153-194) + _spawn (398-416)
@@ -1047,10 +1265,13 @@ void generator_step(E* e) {
     for (int dd = G.current_day + 1; dd <= new_day; dd++) generate_day(e, dd);
     G.current_day = new_day;
     e->C.created_internal = 0; e->C.created_through = 0;
+    e->C.created_service_food = 0; e->C.created_service_waste = 0;
   }
   std::vector<Trip> keep, spawn;
   for (const Trip& t : G.pending) (prev < t.depart && t.depart <= e->C.elapsed ? spawn : keep).push_back(t);
   for (const Trip& t : spawn) {
+    if (e->fatal) break;
+    if (t.kind == TS_TRIP_SERVICE_FOOD || t.kind == TS_TRIP_SERVICE_WASTE) { spawn_service(e, t); continue; }
     if (t.kind == TS_POP_INTERNAL) e->C.created_internal++; else e->C.created_through++;
     (void)e->rng_global.randint(0, 9999);  // the id suffix: vid = f"V_{depart:06d}_{randint(0, 9999):04d}"
     int32_t s[2] = {t.origin % e->W, t.origin / e->W}, g[2] = {t.dest % e->W, t.dest / e->W};
@@ -1105,6 +1326,7 @@ void tick(E* e) {
     std::swap(keys[i], keys[j]);
   }
   for (int k : keys) {
+    if (e->fatal) return;
     SchedEntry se = e->sched[k];
     if (!se.alive) continue;
     switch (se.kind) {
@@ -1112,6 +1334,7 @@ void tick(E* e) {
       case TS_AGENT_LIGHT_GROUP: group_step(e, se.ref); break;
       case TS_AGENT_RAIN_MANAGER: rain_manager_step(e); break;
       case 5: rain_agent_step(e, se.ref); break;
+      case TS_AGENT_CITY_BLOCK: block_step(e, se.ref); break;
       case TS_AGENT_CLOCK:
         if (e->gen.armed) generator_step(e);
         else e->C.elapsed += e->P.time_per_step_seconds;
@@ -1247,6 +1470,8 @@ int tso_schedule_add(ts_handle e, int32_t kind, int32_t count) {
     if (kind == TS_AGENT_LIGHT_GROUP) {
       if (e->groups_scheduled >= (int)e->groups.size()) return fail(e, TS_E_INVALID, "more group slots than groups");
       se.ref = e->groups_scheduled++;
+    } else if (kind == TS_AGENT_CITY_BLOCK) {
+      se.ref = e->gen.blocks_scheduled++;
     } else if (kind != TS_AGENT_NOOP && kind != TS_AGENT_CLOCK && kind != TS_AGENT_RAIN_MANAGER) return fail(e, TS_E_INVALID, "bad agent kind");
     e->sched.push_back(se);
   }
@@ -1281,6 +1506,32 @@ int tso_set_traffic_generator(ts_handle e, const TsTrafficTables* t) {
   if ((G.hw_in.empty() || G.hw_out.empty()) && t->passing_population_per_day > 0)
     return fail(e, TS_E_UNSUPPORTED, "through traffic needs highway entrances and exits");
   for (int z = 0; z < t->n_zones; z++) if (t->zones[z].n_internal < 0 || t->zones[z].n_internal > 8) return TS_E_INVALID;
+  G.blocks.clear();
+  if (t->blk_inner_cells) {
+    if (!t->blk_service_off || !t->blk_service_xy) return fail(e, TS_E_INVALID, "blk_service_* tables missing");
+    G.blocks.resize(t->n_blocks);
+    for (int b = 0; b < t->n_blocks; b++) {
+      Block& B = G.blocks[b];
+      B.cells = t->blk_inner_cells[b];
+      B.needs_food = (t->needs_food_type_mask >> t->blk_type[b]) & 1;
+      B.produces_waste = (t->produces_waste_type_mask >> t->blk_type[b]) & 1;
+      B.max_food = (double)B.cells * t->food_capacity_per_cell;
+      B.max_waste = (double)B.cells * t->waste_capacity_per_cell;
+      B.food = B.max_food; B.waste = 0.0;
+      B.food_rate = (double)B.cells / (double)t->food_consumption_ticks;
+      B.waste_rate = (double)B.cells / (double)t->waste_production_ticks;
+      for (int k = t->blk_service_off[b]; k < t->blk_service_off[b + 1]; k++) {
+        int c;
+        if (!cellxy(t->blk_service_xy, k, c)) return fail(e, TS_E_INVALID, "service road cell out of bounds");
+        B.service_cells.push_back(c);
+      }
+    }
+  }
+  const int n_sv = t->total_service_vehicles_food + t->total_service_vehicles_waste;
+  if (n_sv < 0 || t->total_service_vehicles_food < 0 || t->total_service_vehicles_waste < 0) return TS_E_INVALID;
+  if (n_sv > 0 && (G.blocks.empty() || G.hw_in.empty()))
+    return fail(e, TS_E_UNSUPPORTED, "service vehicles need the block tables and highway entrances");
+  G.sv_live.assign(n_sv, 0);
   G.pending.clear();
   G.current_day = 0;
   G.armed = true;
@@ -1334,6 +1585,7 @@ int tso_add_vehicles(ts_handle e, int32_t n, const int32_t* start_xy, const int3
     v.target = goal_xy[2 * i + 1] * W + goal_xy[2 * i];
     v.pop_type = population_type ? population_type[i] : TS_POP_UNDEFINED;
     v.depart_time = e->P.enable_traffic ? e->C.elapsed : 0.0;
+    v.svc_type = e->svc_pending_type;
     e->veh.push_back(v);
     // place_vehicle (city_model.py:1897-1918)
     e->active.push_back(vid);
@@ -1343,7 +1595,11 @@ int tso_add_vehicles(ts_handle e, int32_t n, const int32_t* start_xy, const int3
     e->veh_sched.push_back((int)e->sched.size());
     e->sched.push_back(SchedEntry{100, vid, true});
     if (e->veh[vid].pop_type == TS_POP_INTERNAL) e->C.live_internal++;
-    else if (e->veh[vid].pop_type == TS_POP_THROUGH) e->C.live_through++;
+    else if (e->veh[vid].pop_type == TS_POP_THROUGH) {
+      e->C.live_through++;
+      if (e->veh[vid].svc_type == TS_TRIP_SERVICE_FOOD) e->C.live_service_food++;
+      else if (e->veh[vid].svc_type == TS_TRIP_SERVICE_WASTE) e->C.live_service_waste++;
+    }
     // self.path = self._compute_path() (vehicle_base.py:80-81)
     std::vector<int> p;
     if (path_off) {
@@ -1390,8 +1646,9 @@ int tso_upload_map(ts_handle e, int32_t which, const int8_t* src) {
 
 int tso_step(ts_handle e, int32_t n_ticks) {
   if (!e || n_ticks < 0) return TS_E_INVALID;
+  if (e->fatal) return e->fatal;
   if (!e->seeded[0] || !e->seeded[1]) return fail(e, TS_E_STATE, "both RNG streams must be seeded before step");
-  for (int t = 0; t < n_ticks; t++) tick(e);
+  for (int t = 0; t < n_ticks; t++) { tick(e); if (e->fatal) return e->fatal; }
   return TS_OK;
 }
 
@@ -1487,6 +1744,12 @@ int tso_download_groups(ts_handle e, int32_t* rows) {
   return (int)e->groups.size();
 }
 
+int tso_num_blocks(ts_handle e) { return e ? (int)e->gen.blocks.size() : TS_E_INVALID; }
+int tso_download_blocks(ts_handle e, double* rows) {
+  if (!e || !rows) return TS_E_INVALID;
+  for (size_t b = 0; b < e->gen.blocks.size(); b++) { rows[2 * b] = e->gen.blocks[b].food; rows[2 * b + 1] = e->gen.blocks[b].waste; }
+  return TS_OK;
+}
 int tso_counters(ts_handle e, TsCounters* out) {
   if (!e || !out) return TS_E_INVALID;
   *out = e->C;

@@ -87,8 +87,17 @@ SCENARIOS = {
                         defaults={"INTERNAL_POPULATION_TRAFFIC_PER_DAY": 0, "PASSING_POPULATION_TRAFFIC_PER_DAY": 0,
                                   "TOTAL_SERVICE_VEHICLES_FOOD": 0, "TOTAL_SERVICE_VEHICLES_WASTE": 0, **GATED,
                                   "RAIN_RADIUS_MIN": 10, "RAIN_RADIUS_MAX": 30, "RAIN_SPAWN_CHANCE": 0.2}),
-    # config 1: everything on (rain, traffic generator, service vehicles) - "next" rows
-    "config1_64_s11": dict(size=64, seed=11, vehicles=50, ticks=100, defaults={}),
+    # "next" row 3: service vehicles + CityBlock food / waste (rain off); long enough for several service trips
+    "service_64_s15": dict(size=64, seed=15, vehicles=10, ticks=900, defaults={"RAIN_ENABLED": False}),
+    # the same with a large fleet: several vehicles servicing at once (parked blockers, contested service cells,
+    # decide-phase arrivals), strandings frequent
+    "service_heavy_96_s16": dict(size=96, seed=16, vehicles=20, ticks=500,
+                                 defaults={"RAIN_ENABLED": False, "INTERNAL_POPULATION_TRAFFIC_PER_DAY": 3000,
+                                           "PASSING_POPULATION_TRAFFIC_PER_DAY": 1500,
+                                           "TOTAL_SERVICE_VEHICLES_FOOD": 600, "TOTAL_SERVICE_VEHICLES_WASTE": 600,
+                                           "VEHICLE_MALFUNCTION_CHANCE": 0.002, "VEHICLE_MALFUNCTION_DURATION": 25}),
+    # config 1 of BASELINE.json: everything on (rain, traffic generator, service vehicles, city blocks)
+    "config1_64_s11": dict(size=64, seed=11, vehicles=50, ticks=500, defaults={}),
 }
 
 
@@ -209,6 +218,31 @@ def world_tables(m):
     types = list(Defaults_AVAILABLE)
     out["blk_type"] = np.asarray([types.index(b.block_type) for b in blocks], dtype=np.int32)
     out["blk_entr_off"], out["blk_entr_xy"] = ragged([[c for e in b.get_entrances() for c in e.position] for b in blocks], 2)
+    out["blk_inner_cells"] = np.asarray([len(b.get_inner_blocks()) for b in blocks], dtype=np.int32)
+    # CityBlock.get_service_road_cell (city_block.py:152-202) ranks a Python *set* of road cells with a stable sort,
+    # so ties fall in CPython's set-iteration order.  Everything up to the ranking is static: replay the very same
+    # sequence of set operations here, in the real interpreter, and record the ranked list per block.
+    def ranked_service_cells(b):
+        sidewalk_coords = [sw.get_position() for sw in b._sidewalks]
+        candidates = set()
+        for sx, sy in sidewalk_coords:
+            for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                rx, ry = sx + dx, sy + dy
+                if not m.in_bounds(rx, ry):
+                    continue
+                agents = m.get_cell_contents(rx, ry)
+                if agents and agents[0].cell_type in _D.ROADS:
+                    candidates.add((rx, ry))
+        if not candidates:
+            return []
+        entrance_coords = [e.get_position() for e in b._entrances]
+        for ex, ey in entrance_coords:
+            for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                candidates.discard((ex + dx, ey + dy))
+        if not candidates or not entrance_coords:
+            return []
+        return sorted(candidates, key=lambda rc: min(abs(rc[0] - ex) + abs(rc[1] - ey) for ex, ey in entrance_coords))
+    out["blk_service_off"], out["blk_service_xy"] = ragged([[c for rc in ranked_service_cells(b) for c in rc] for b in blocks], 2)
     out["block_entrances_xy"] = np.asarray([c.position for c in m.block_entrances], dtype=np.int32).reshape(-1, 2)
     out["highway_entrances_xy"] = np.asarray([c.position for c in m.highway_entrances], dtype=np.int32).reshape(-1, 2)
     out["highway_exits_xy"] = np.asarray([c.position for c in m.highway_exits], dtype=np.int32).reshape(-1, 2)
@@ -225,7 +259,8 @@ GRP_FIELDS = ["current_phase", "pending_phase", "queue_timer", "gap_timer", "las
 CNT_FIELDS = ["stuck", "collisions", "malfunctions", "overtaking", "in_stuck_detour", "parked",
               "live_internal", "live_through", "count_completed_internal", "count_completed_through",
               "total_distance_internal", "total_distance_through", "errored_internal", "errored_through",
-              "created_internal", "created_through"]
+              "created_internal", "created_through", "live_service_food", "live_service_waste",
+              "created_service_food", "created_service_waste"]
 
 
 def veh_row(v):
@@ -324,7 +359,12 @@ def run_scenario(name):
         P_int=int(Defaults.INTERNAL_POPULATION_TRAFFIC_PER_DAY), P_thr=int(Defaults.PASSING_POPULATION_TRAFFIC_PER_DAY),
         dt=int(Defaults.TIME_PER_STEP_IN_SECONDS),
         start_offset=int(Defaults.SIMULATION_STARTING_TIME_OF_DAY_HOURS * 3600 + Defaults.SIMULATION_STARTING_TIME_OF_DAY_MINUTES * 60),
-        pending_day0=(len(dta0.pending) if dta0 is not None else 0))))
+        pending_day0=(len(dta0.pending) if dta0 is not None else 0),
+        service_food=int(Defaults.TOTAL_SERVICE_VEHICLES_FOOD), service_waste=int(Defaults.TOTAL_SERVICE_VEHICLES_WASTE),
+        max_load_food=float(Defaults.SERVICE_VEHICLE_MAX_LOAD_FOOD), max_load_waste=float(Defaults.SERVICE_VEHICLE_MAX_LOAD_WASTE),
+        load_time=int(Defaults.SERVICE_VEHICLE_LOAD_TIME), gradual=bool(Defaults.GRADUAL_CITY_BLOCK_RESOURCES),
+        food_capacity_per_cell=float(Defaults.FOOD_CAPACITY_PER_CELL), waste_capacity_per_cell=float(Defaults.WASTE_CAPACITY_PER_CELL),
+        food_consumption_ticks=int(Defaults.FOOD_CONSUMPTION_TICKS), waste_production_ticks=int(Defaults.WASTE_PRODUCTION_TICKS))))
     out["sched_rng_initial"] = np.asarray(m.random.getstate()[1], dtype=np.uint32)
     v_start, v_goal, v_path_off, v_path_flat = [], [], [0], []
     vehicles = []
@@ -359,7 +399,7 @@ def run_scenario(name):
     VehicleAgent.__init__ = init
 
     T = spec["ticks"]
-    occ_t, stop_t, stuck_t, rain_t, rain_rows = [], [], [], [], []
+    occ_t, stop_t, stuck_t, rain_t, rain_rows, blk_rows = [], [], [], [], [], []
     veh_rows, veh_off = [], [0]
     grp_rows = []
     cnt_rows = []
@@ -368,15 +408,22 @@ def run_scenario(name):
     nsched = []
     dta = getattr(m, "dynamic_traffic_generator", None)
     dens_ticks = {}
+    raised = None
     for t in range(T):
         c0 = calls["n"]
-        m.step()
+        try:
+            m.step()
+        except Exception as ex:  # the reference itself raised inside model.step(): record where, replay expects an error there
+            raised = (t, f"{type(ex).__name__}: {ex}")
+            T = t
+            break
         astar_per_tick.append(calls["n"] - c0)
         occ_t.append(np.packbits(m.occupancy_map.astype(np.uint8).ravel()))
         stop_t.append(np.packbits(m.stop_map.astype(np.uint8).ravel()))
         stuck_t.append(np.packbits(m.stuck_map.astype(np.uint8).ravel()))
         rain_t.append(np.packbits((m.rain_map > 0).astype(np.uint8).ravel()))
         rm = getattr(m, "rain_manager", None)
+        blk_rows.append([[float(b.get_food_units()), float(b.get_waste_units())] for b in getattr(m, "city_blocks", {}).values()])
         rain_rows.append([len(m.rains), rm.counter if rm else 0, rm.cooldown if rm else 0,
                           sum(r.radius for r in m.rains), int(sum(int(r.x) + int(r.y) for r in m.rains))])
         for v in m.active_vehicle_agents:
@@ -390,13 +437,14 @@ def run_scenario(name):
         s_fp = _rng_fp(m.random.getstate())
         rng_rows.append([g_fp[0], g_fp[1], s_fp[0], s_fp[1]])
         nsched.append(len(m.schedule._agents))
-        if t in (0, T // 2):
+        if t in (0, spec["ticks"] // 2):
             dens_ticks[t] = m.density_map32.copy()
     out["occ_t"] = np.stack(occ_t)
     out["stop_t"] = np.stack(stop_t)
     out["stuck_t"] = np.stack(stuck_t)
     out["rain_t"] = np.stack(rain_t)
     out["rain_rows"] = np.asarray(rain_rows, dtype=np.int64)
+    out["blk_rows"] = np.asarray(blk_rows, dtype=np.float64)
     out["rain_params"] = np.asarray(json.dumps(dict(
         enabled=bool(Defaults.RAIN_ENABLED), radius_min=int(Defaults.RAIN_RADIUS_MIN), radius_max=int(Defaults.RAIN_RADIUS_MAX),
         occurrences_max=int(Defaults.RAIN_OCCURRENCES_MAX), cooldown=int(Defaults.RAIN_COOLDOWN),
@@ -410,6 +458,9 @@ def run_scenario(name):
     out["nsched_t"] = np.asarray(nsched, dtype=np.int32)
     for t, d in dens_ticks.items():
         out[f"density_t{t}"] = d
+    if raised is not None:
+        out["raised_at_tick"] = np.int32(raised[0])
+        out["raised_message"] = np.asarray(raised[1][:200])
     out["veh_fields"] = np.asarray(json.dumps(VEH_FIELDS))
     out["grp_fields"] = np.asarray(json.dumps(GRP_FIELDS))
     out["cnt_fields"] = np.asarray(json.dumps(CNT_FIELDS))

@@ -23,6 +23,7 @@ def trace_path(name):
 
 DTA_TRACES = ["dta_64_s12", "dta_96_s13"]
 RAIN_TRACES = ["rain_96_s14"]
+SERVICE_TRACES = ["service_64_s15", "service_heavy_96_s16", "config1_64_s11"]
 
 
 def setup_from_trace(api, tr, explicit_paths=False):
@@ -33,7 +34,7 @@ def setup_from_trace(api, tr, explicit_paths=False):
         build_engine(api, tr, defaults=tr["defaults_json"], global_state=tr["global_rng_before_day0"],
                      sched_state=tr["sched_rng_initial"])
         api.set_traffic_generator(tr, internal_per_day=dta["P_int"], passing_per_day=dta["P_thr"],
-                                  start_offset_seconds=dta["start_offset"])
+                                  start_offset_seconds=dta["start_offset"], service=dta)
         import zlib
         want = np.asarray(tr["global_rng_after_worldgen"], dtype=np.uint64)
         got = api.rng_state(capi.RNG_GLOBAL)
@@ -109,6 +110,19 @@ def replay_and_compare(api, tr, ticks=None, check_rng=True, check_counters=True)
             names = tr["cnt_fields"]
             wantc = dict(zip(names, tr["cnt_rows"][t]))
             for nme in ("stuck", "collisions", "malfunctions", "overtaking", "in_stuck_detour", "parked",
-                        "live_through", "count_completed_through", "total_distance_through"):
-                assert getattr(c, nme) == wantc[nme], f"{ctx}: counter {nme}: {getattr(c, nme)} != {wantc[nme]}"
+                        "live_through", "count_completed_through", "total_distance_through",
+                        "live_service_food", "live_service_waste", "created_service_food", "created_service_waste"):
+                if nme in wantc:
+                    assert getattr(c, nme) == wantc[nme], f"{ctx}: counter {nme}: {getattr(c, nme)} != {wantc[nme]}"
+        if "blk_rows" in tr and api.num_blocks():
+            b_got, b_want = api.blocks(), tr["blk_rows"][t]
+            assert np.array_equal(b_got, b_want), f"{ctx}: block food/waste: got {b_got.tolist()} want {b_want.tolist()}"
+    if "raised_at_tick" in tr and T == int(tr["raised_at_tick"]):
+        # the reference itself raised inside model.step() at this tick: the engine reports an error there too
+        try:
+            api.step(1)
+        except capi.EngineError as ex:
+            assert ex.code == capi.TS_E_UNSUPPORTED, ex
+        else:
+            raise AssertionError(f"tick {T}: the reference raised ({tr['raised_message']}), the engine did not")
     return T

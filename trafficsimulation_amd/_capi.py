@@ -19,7 +19,7 @@ LIGHT_ALGORITHMS = {
     "DISABLED": 0, "FIXED_TIME": 1, "QUEUE_ACTUATED": 2, "PRESSURE_CONTROL": 3,
     "NEIGHBOR_PRESSURE_CONTROL": 4, "NEIGHBOR_GREEN_WAVE": 5,
 }
-AGENT_LIGHT_GROUP, AGENT_NOOP, AGENT_RAIN_MANAGER, AGENT_CLOCK = 0, 1, 2, 3
+AGENT_LIGHT_GROUP, AGENT_NOOP, AGENT_RAIN_MANAGER, AGENT_CLOCK, AGENT_CITY_BLOCK = 0, 1, 2, 3, 6
 MAP_OCCUPANCY, MAP_STOP, MAP_STUCK, MAP_RAIN = 0, 1, 2, 3
 RNG_GLOBAL, RNG_SCHEDULER = 0, 1
 POP = {"undefined": 0, "internal": 1, "through": 2}
@@ -83,7 +83,8 @@ class TsCounters(C.Structure):
         ("total_duration_internal", C.c_double), ("total_duration_through", C.c_double), ("elapsed", C.c_double)] + [
         (n, C.c_int64) for n in ("step_count", "agent_steps", "astar_calls", "astar_expansions",
                                  "astar_relaxations", "move_rounds", "rng_fixups", "created_internal",
-                                 "created_through")]
+                                 "created_through", "created_service_food", "created_service_waste",
+                                 "live_service_food", "live_service_waste")]
 
 
 class TsTrafficZone(C.Structure):
@@ -97,7 +98,14 @@ class TsTrafficTables(C.Structure):
                 ("blk_entr_xy", C.c_void_p), ("n_highway_entrances", C.c_int32), ("highway_entrances_xy", C.c_void_p),
                 ("n_highway_exits", C.c_int32), ("highway_exits_xy", C.c_void_p),
                 ("internal_population_per_day", C.c_int32), ("passing_population_per_day", C.c_int32),
-                ("start_offset_seconds", C.c_int32), ("n_zones", C.c_int32), ("zones", TsTrafficZone * 8)]
+                ("start_offset_seconds", C.c_int32), ("n_zones", C.c_int32), ("zones", TsTrafficZone * 8),
+                ("total_service_vehicles_food", C.c_int32), ("total_service_vehicles_waste", C.c_int32),
+                ("service_load_time", C.c_int32), ("gradual_city_block_resources", C.c_int32),
+                ("food_consumption_ticks", C.c_int32), ("waste_production_ticks", C.c_int32),
+                ("needs_food_type_mask", C.c_int32), ("produces_waste_type_mask", C.c_int32),
+                ("service_max_load_food", C.c_double), ("service_max_load_waste", C.c_double),
+                ("food_capacity_per_cell", C.c_double), ("waste_capacity_per_cell", C.c_double),
+                ("blk_inner_cells", C.c_void_p), ("blk_service_off", C.c_void_p), ("blk_service_xy", C.c_void_p)]
 
 
 # Defaults.TIME_ZONES (config.py:155-236) with block types as indices into AVAILABLE_CITY_BLOCKS
@@ -186,7 +194,7 @@ class CApi:
         f("default_params").restype = None
         f("last_error").restype = C.c_char_p
         f("last_error").argtypes = [C.c_void_p]
-        for name in ("destroy", "num_vehicles", "num_groups", "num_scheduled"):
+        for name in ("destroy", "num_vehicles", "num_groups", "num_scheduled", "num_blocks"):
             f(name).argtypes = [C.c_void_p]
         f("create").argtypes = [C.POINTER(TsWorld), C.POINTER(TsParams), C.POINTER(C.c_void_p)]
         f("set_lights").argtypes = [C.c_void_p, C.POINTER(TsLightTables)]
@@ -204,6 +212,7 @@ class CApi:
         f("download_vehicles").argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         f("download_path").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         f("download_groups").argtypes = [C.c_void_p, C.c_void_p]
+        f("download_blocks").argtypes = [C.c_void_p, C.c_void_p]
         f("counters").argtypes = [C.c_void_p, C.POINTER(TsCounters)]
         f("astar").argtypes = [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p, C.c_int32]
         f("debug_set_occupancy").argtypes = [C.c_void_p, C.c_void_p]
@@ -292,7 +301,7 @@ class CApi:
         self.n_groups = t.n_groups
 
     def set_traffic_generator(self, tables: dict, internal_per_day=10000, passing_per_day=2400,
-                              start_offset_seconds=6 * 3600, zones=None):
+                              start_offset_seconds=6 * 3600, zones=None, service: Optional[dict] = None):
         """DynamicTrafficAgent.__init__: `tables` carries blk_type / blk_entr_off / blk_entr_xy /
         highway_entrances_xy / highway_exits_xy (golden world-table keys).  Generates day 0 (global stream)."""
         t = TsTrafficTables()
@@ -313,6 +322,24 @@ class CApi:
             z.start_hour, z.end_hour, z.through_distribution, z.n_internal = h0, h1, thr, len(pairs)
             for k, (o, dd, fr) in enumerate(pairs):
                 z.origin_type[k], z.dest_type[k], z.fraction[k] = _BT[o], _BT[dd], fr
+        if "blk_inner_cells" in tables:
+            service = service or {}
+            keep["bi"] = _i32(tables["blk_inner_cells"])
+            keep["so"], keep["sx"] = _i32(tables["blk_service_off"]), _i32(tables["blk_service_xy"])
+            t.blk_inner_cells, t.blk_service_off, t.blk_service_xy = (
+                keep["bi"].ctypes.data, keep["so"].ctypes.data, keep["sx"].ctypes.data)
+            t.total_service_vehicles_food = int(service.get("service_food", 0))
+            t.total_service_vehicles_waste = int(service.get("service_waste", 0))
+            t.service_load_time = int(service.get("load_time", 20))
+            t.gradual_city_block_resources = int(service.get("gradual", True))
+            t.food_consumption_ticks = int(service.get("food_consumption_ticks", 50))
+            t.waste_production_ticks = int(service.get("waste_production_ticks", 100))
+            t.needs_food_type_mask = int(service.get("needs_food_type_mask", 0b01100))
+            t.produces_waste_type_mask = int(service.get("produces_waste_type_mask", 0b11111))
+            t.service_max_load_food = float(service.get("max_load_food", 50.0))
+            t.service_max_load_waste = float(service.get("max_load_waste", 250.0))
+            t.food_capacity_per_cell = float(service.get("food_capacity_per_cell", 2.0))
+            t.waste_capacity_per_cell = float(service.get("waste_capacity_per_cell", 1.5))
         self._chk(self._f("set_traffic_generator")(self.h, C.byref(t)))
 
     def schedule_add(self, kind: int, count: int = 1):
@@ -426,6 +453,16 @@ class CApi:
         n = self._chk(self._f("num_groups")(self.h))
         out = np.zeros((max(n, 1), len(G_FIELDS)), dtype=np.int32)
         self._chk(self._f("download_groups")(self.h, out.ctypes.data))
+        return out[:n]
+
+    def num_blocks(self) -> int:
+        return self._chk(self._f("num_blocks")(self.h))
+
+    def blocks(self) -> np.ndarray:
+        """(food_units, waste_units) per CityBlock, city_blocks order."""
+        n = self._chk(self._f("num_blocks")(self.h))
+        out = np.zeros((max(n, 1), 2), dtype=np.float64)
+        self._chk(self._f("download_blocks")(self.h, out.ctypes.data))
         return out[:n]
 
     def counters(self) -> TsCounters:

@@ -338,7 +338,7 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
     }
     if (idx_veh == 0) {
       int bk = d.cell_veh[S.A[0]];
-      if (bk >= 0 && (seen_stranded(d, bk, v.i) || (d.flags[bk] & VF_PARKED))) {
+      if (bk >= 0 && (seen_stranded(d, bk, v.i) || seen_parked(d, bk, v.i))) {
         int bt = -1, idx_bp = -1;
         for (int q = 0; q < la; q++) if (d.occ[S.A[q]] == 0) { bt = S.A[q]; idx_bp = q; break; }
         if (bt >= 0) {
@@ -472,7 +472,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
     if (!early && d.stop[v.pos] == 1) { v.base = 0; v.cur = 0; early = true; }
   }
   int max_steps = d.max_steps[vid];
-  bool path_changed = false, reached_body = false;
+  bool path_changed = false, reached_body = false, arrived = false;
   v.newpath = false;
   v.d_overtaking = 0; v.d_detour = 0;
   for (int k = 0; k < 4; k++) { v.ax_staged[k] = false; v.ax_len[k] = 0; }
@@ -516,7 +516,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
     if (!done_obst && v.cooldown > 0) {
       if (idx_veh == 0) {
         int b = d.cell_veh[first_cell];
-        if (b >= 0 && (seen_stranded(d, b, i) || (d.flags[b] & VF_PARKED))) {
+        if (b >= 0 && (seen_stranded(d, b, i) || seen_parked(d, b, i))) {
           // immediate pathfinding
         } else { v.cooldown -= 1; done_obst = true; }
       } else { v.cooldown -= 1; done_obst = true; }
@@ -546,7 +546,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
     v.f = blocked ? (v.f | VF_BLOCKED) : (v.f & ~VF_BLOCKED);
     if (ms <= 0) {
       v.base = 0;
-      if (v.pos == v.target) atomicExch(&d.cnt->error, TS_E_UNSUPPORTED);  // despawn inside decide (start == goal)
+      if (v.pos == v.target) arrived = true;   // on_target_reached() inside step_decide (657-661)
       early = true;
     }
     reached_body = true;
@@ -584,6 +584,22 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
   d.base_speed[vid] = (int8_t)v.base;
   d.cur_speed[vid] = (int8_t)v.cur;
   d.flags[vid] = early ? (v.f | VF_EARLY) : v.f;
+  if (arrived) {
+    if (!(v.f & VF_KEEP)) atomicExch(&d.cnt->error, TS_E_UNSUPPORTED);  // despawn inside decide (start == goal)
+    else if (v.f & VF_TOBLOCK) svc_record(d, i, vid, AR_DECIDE);        // ServiceVehicleAgent._start_service
+    else {   // base on_target_reached of a vehicle that stays: trip statistics once more, then _park()
+      if (P.enable_traffic && d.pop[vid] == TS_POP_THROUGH) {
+        atomicAdd(&d.cnt->dur_through, d.elapsed - d.depart[vid]);
+        atomicAdd((unsigned long long*)&d.cnt->dist_through, (unsigned long long)d.steps[vid]);
+        atomicAdd((unsigned long long*)&d.cnt->completed_through, 1ULL);
+      } else if (P.enable_traffic && d.pop[vid] == TS_POP_INTERNAL) {
+        atomicAdd(&d.cnt->dur_internal, d.elapsed - d.depart[vid]);
+        atomicAdd((unsigned long long*)&d.cnt->dist_internal, (unsigned long long)d.steps[vid]);
+        atomicAdd((unsigned long long*)&d.cnt->completed_internal, 1ULL);
+      }
+      if (!(v.f & VF_PARKED)) svc_record(d, i, vid, AR_DECIDE);
+    }
+  }
   return DV_DONE;
 }
 
@@ -668,7 +684,7 @@ __global__ void k_spawn_plan(Dev d, TsParams P, ATier t, int vid, int32_t* statu
   AScratch S;
   scratch_bind(t, 0, S);
   VW v;
-  v.vid = vid; v.i = d.active_idx[vid]; v.pos = d.pos[vid]; v.target = d.target[vid];
+  v.vid = vid; v.i = LAST_IDX; v.pos = d.pos[vid]; v.target = d.target[vid];
   v.f = d.flags[vid]; v.base = 0; v.cur = 0; v.cooldown = P.pathfinding_cooldown;
   v.over_dur = d.over_dur[vid]; v.det_dur = d.det_dur[vid]; v.stuck_ticks = d.stuck_ticks[vid];
   v.newpath = false; v.plen = 0; v.pcur = 0; v.off = 0; v.d_overtaking = 0; v.d_detour = 0;

@@ -12,7 +12,14 @@ namespace {
 constexpr uint16_t VF_EARLY = TS_F_EARLY_EXIT, VF_STUCK = TS_F_STUCK, VF_PARKED = TS_F_PARKED,
                    VF_COLL = TS_F_COLLISION, VF_MALF = TS_F_MALFUNCTION, VF_OVER = TS_F_OVERTAKING,
                    VF_DETOUR = TS_F_DETOUR, VF_BLOCKED = TS_F_BLOCKED, VF_HASPREV = TS_F_HAS_PREV,
-                   VF_KEEP = 512 /* remove_on_arrival == False */, VF_ALIVE = 1024;
+                   VF_KEEP = 512 /* remove_on_arrival == False */, VF_ALIVE = 1024,
+                   // ServiceVehicleAgent (vehicle_service.py): phase "to_block" = SVC|TOBLOCK, "servicing" = SVC|SERVICING,
+                   // "to_exit" = SVC alone
+                   VF_SVC = 2048, VF_SERVICING = 4096, VF_TOBLOCK = 8192;
+constexpr int LAST_IDX = 0x7FFFFFFF;  // "decides after everyone": planners that run outside the decide phase
+// service records the kernels hand to the host (key, vehicle, what)
+constexpr int AR_START = 0 /* _start_service in the move phase, key = rank */, AR_DECIDE = 1 /* on_target_reached inside
+                   step_decide, key = decide-order index: applied by k_decide_arrive */, AR_DESPAWN = 2 /* service vehicle left */;
 constexpr int8_t K_VEHICLE = 100, K_DEAD = -1, K_RAIN = 5;  // K_RAIN: a RainAgent's schedule entry
 constexpr uint32_t RANK_BITS = 22, RANK_MASK = (1u << RANK_BITS) - 1, EPOCHS = 1u << (32 - RANK_BITS);
 constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
@@ -27,7 +34,7 @@ struct DevCnt {
   double dur_internal, dur_through;
   int resolved;    // agents stepped so far in this move phase
   int deaths;      // vehicles removed this tick
-  int need_astar;  // unused (kept for layout)
+  int arr_n;       // service records written this tick (Dev::arr)
   int error;       // sticky device-side error
   int replan_n[6]; // work-list lengths: first tier, second, third, pool-full retries, beyond the last tier, LDS-tier overflow
   unsigned long long pool_used;  // words handed out from the path pool (device-side bump allocator)
@@ -40,6 +47,7 @@ struct DevCnt {
 
 struct Dev {
   int W, H, N;
+  double elapsed;   // DynamicTrafficAgent.elapsed as the decide phase sees it (before the clock agent steps)
   int8_t *occ, *stop, *stuck, *rain;
   uint8_t* allowed;
   int8_t *is_road, *road_type, *inter;
@@ -68,6 +76,9 @@ struct Dev {
   int8_t* sched_kind;
   int32_t* sched_ref;
   int32_t* hslot;     // schedule slot of every host-side agent (rain manager, rain clouds), kept by compaction
+  int32_t* bslot;     // schedule slot of every CityBlock, kept by compaction
+  int32_t* arr;       // service records, 3 ints each (see AR_*)
+  int arr_cap;
   uint32_t* rank;     // per schedule slot
   uint8_t* resolved;  // per schedule slot, this move phase
   // light groups (CSR tables + state)
@@ -113,5 +124,23 @@ __device__ __forceinline__ bool seen_stranded(const Dev& d, int ag, int my_idx) 
   return d.st_before[ag] != 0;
 }
 
+// blocker.is_parked as vehicle number my_idx of the decide order sees it: a remove_on_arrival=False vehicle that sits
+// on its target parks inside its own step_decide (vehicle_base.py:657-661 -> on_target_reached -> _park); the flag
+// itself is only written after the decide kernels (k_decide_arrive), so earlier deciders are recognised here.
+__device__ __forceinline__ bool seen_parked(const Dev& d, int ag, int my_idx) {
+  const uint16_t af = d.flags[ag];
+  if (af & VF_PARKED) return true;
+  if (!(af & VF_KEEP) || my_idx == LAST_IDX || d.active_idx[ag] >= my_idx) return false;
+  const int p = d.pos[ag];
+  if (p != d.target[ag]) return false;
+  const uint8_t e = d.ev[ag];
+  if (e == 1 || e == 3 || d.st_after[ag]) return false;   // stranded at its own decide point: it returned early
+  return d.stop[p] != 1;
+}
+
+__device__ __forceinline__ void svc_record(const Dev& d, int key, int vid, int what) {
+  const int k = atomicAdd(&d.cnt->arr_n, 1);
+  if (k < d.arr_cap) { d.arr[3 * k] = key; d.arr[3 * k + 1] = vid; d.arr[3 * k + 2] = what; }
+}
 
 }  // namespace

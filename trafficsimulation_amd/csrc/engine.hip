@@ -71,6 +71,7 @@ __global__ void k_decide_pre(Dev d, TsParams P, int start, int n_active) {
             bool ag_str = earlier ? (d.ev[ag] ? true : ((ag_sb && d.stranded_left[ag] - 1 > 0) || !P.malfunction_active)) : ag_sb;
             bool cs_pos = earlier ? (!ag_str && d.stop[d.pos[ag]] != 1) : (d.cur_speed[ag] > 0);
             if (!cs_pos || (af & (VF_STUCK | VF_PARKED)) || ag_str) continue;
+            if (earlier && (af & VF_KEEP) && d.pos[ag] == d.target[ag]) continue;   // it parked inside its own step_decide
             if (d.dir[ag] != opposite) continue;
             cand = ag;
             break;
@@ -159,6 +160,7 @@ __global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix, co
     const int vid = d.sched_ref[s];
     const uint16_t f = d.flags[vid];
     const int pos = d.pos[vid];
+    if (f & VF_SERVICING) return;   // ServiceVehicleAgent.step only counts down (vehicle_service.py:43-49)
     if (f & VF_EARLY) {
       if (d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED) claim(d.claims, (pos) * 4 + 3, key);  // tick_stuck reads stop[pos]
       if (pos == d.target[vid]) claim(d.claims, (pos) * 4 + 0, key);
@@ -213,7 +215,14 @@ __device__ __forceinline__ void cell_append(const Dev& d, int cell, int vid) {
 
 // on_target_reached (vehicle_base.py:755-775) -> _despawn -> CityModel.remove_vehicle (city_model.py:1920-1941)
 __device__ void on_target_reached_dev(const Dev& d, const TsParams& P, int vid, int s, int pos, uint16_t& f,
-                                      double elapsed_now) {
+                                      double elapsed_now, int key) {
+  if (f & VF_TOBLOCK) {   // ServiceVehicleAgent.on_target_reached -> _start_service (vehicle_service.py:54-60, 85-104):
+    // park and start the load timer here; the load / block bookkeeping is host state (AR_START record)
+    if (!(f & VF_PARKED)) { f |= VF_PARKED; atomicAdd((unsigned long long*)&d.cnt->parked, 1ULL); }
+    f = (f & ~VF_TOBLOCK) | VF_SERVICING;
+    svc_record(d, key, vid, AR_START);
+    return;
+  }
   if (P.enable_traffic) {
     double duration = elapsed_now - d.depart[vid];
     int pop = d.pop[vid];
@@ -237,16 +246,19 @@ __device__ void on_target_reached_dev(const Dev& d, const TsParams& P, int vid, 
     if (pop == TS_POP_INTERNAL) atomicAdd((unsigned long long*)&d.cnt->live_internal, (unsigned long long)-1LL);
     else if (pop == TS_POP_THROUGH) atomicAdd((unsigned long long*)&d.cnt->live_through, (unsigned long long)-1LL);
     atomicAdd(&d.cnt->deaths, 1);
+    if (f & VF_SVC) svc_record(d, key, vid, AR_DESPAWN);
   } else if (!(f & VF_PARKED)) {
     f |= VF_PARKED;
     atomicAdd((unsigned long long*)&d.cnt->parked, 1ULL);
+    if (f & VF_SVC) svc_record(d, key, vid, AR_START);   // the host keeps the set of cells with a parked vehicle
   }
 }
 
 // VehicleAgent.step with PATHFINDING_BATCHING (vehicle_base.py:666-685): _execute_movement 733-753,
 // _move_to 521-532 + CityModel.move_vehicle (city_model.py:1945-1963), tick_stuck 687-693.
-__device__ void vehicle_step_dev(const Dev& d, const TsParams& P, int vid, int s, double elapsed_now) {
+__device__ void vehicle_step_dev(const Dev& d, const TsParams& P, int vid, int s, double elapsed_now, int key) {
   uint16_t f = d.flags[vid];
+  if (f & VF_SERVICING) return;   // the countdown and _finish_service are host state
   int pos = d.pos[vid];
   if (!(f & VF_EARLY)) {
     const int m = d.max_steps[vid];
@@ -290,7 +302,7 @@ __device__ void vehicle_step_dev(const Dev& d, const TsParams& P, int vid, int s
       }
     }
   }
-  if (pos == d.target[vid]) on_target_reached_dev(d, P, vid, s, pos, f, elapsed_now);
+  if (pos == d.target[vid]) on_target_reached_dev(d, P, vid, s, pos, f, elapsed_now, key);
   d.flags[vid] = f;
 }
 
@@ -410,7 +422,9 @@ __global__ void k_move_resolve(Dev d, TsParams P, int n_sched, uint32_t prefix, 
     const uint16_t f = d.flags[vid];
     const int pos = d.pos[vid];
     const bool lights = d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED;
-    if (f & VF_EARLY) {
+    if (f & VF_SERVICING) {
+      // nothing on the maps is read or written
+    } else if (f & VF_EARLY) {
       if (lights && claim_rank(d.claims[(pos) * 4 + 2], prefix) < r) safe = false;
       if (pos == d.target[vid] && (claim_rank(d.claims[(pos) * 4 + 0], prefix) < r || claim_rank(d.claims[(pos) * 4 + 1], prefix) < r))
         safe = false;
@@ -427,7 +441,7 @@ __global__ void k_move_resolve(Dev d, TsParams P, int n_sched, uint32_t prefix, 
       }
     }
     if (!safe) { out_list[atomicAdd(out_n, 1)] = s; return; }
-    vehicle_step_dev(d, P, vid, s, elapsed0 + (r > rank_clock ? (double)P.time_per_step_seconds : 0.0));
+    vehicle_step_dev(d, P, vid, s, elapsed0 + (r > rank_clock ? (double)P.time_per_step_seconds : 0.0), (int)r);
   } else if (kind == TS_AGENT_LIGHT_GROUP && P.light_algorithm != TS_LIGHTS_DISABLED) {
     const int g = d.sched_ref[s];
     for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1] && safe; k++)
@@ -538,9 +552,18 @@ __global__ void k_compact_scatter(Dev d, int n, int which, const int* block_off,
         int8_t k = d.sched_kind[i];
         int ref = d.sched_ref[i];
         out_kind[dst] = k; out_ref[dst] = ref;
-        if (k == K_VEHICLE) d.sched_slot[ref] = dst;
-        else if (k == TS_AGENT_LIGHT_GROUP) d.g_slot[ref] = dst;
-        else if (k == TS_AGENT_RAIN_MANAGER || k == K_RAIN) d.hslot[ref] = dst;
+        // which table remembers this agent's slot (a plain select: the if / else-if chain with the two-kind arm
+        // was miscompiled for gfx950 by ROCm 7.2's hipcc at -O3, leaving the K_RAIN lane's base pointer undefined)
+        int32_t* tab = nullptr;
+        switch (k) {
+          case K_VEHICLE: tab = d.sched_slot; break;
+          case TS_AGENT_LIGHT_GROUP: tab = d.g_slot; break;
+          case TS_AGENT_RAIN_MANAGER: tab = d.hslot; break;
+          case K_RAIN: tab = d.hslot; break;
+          case TS_AGENT_CITY_BLOCK: tab = d.bslot; break;
+          default: break;
+        }
+        if (tab) tab[ref] = dst;
       }
     }
     __syncthreads();
@@ -675,6 +698,41 @@ __global__ void k_rain_map(int8_t* rain, int W, int H, RainDiscs D) {
 }
 
 // rank[slot] = position of the slot in the shuffled key order
+// on_target_reached inside step_decide for the vehicles that stay (AR_DECIDE records): the flag changes other
+// deciders must not see half-way are applied once the decide kernels are done
+__global__ void k_decide_arrive(Dev d, int n_rec) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_rec || d.arr[3 * k + 2] != AR_DECIDE) return;
+  const int vid = d.arr[3 * k + 1];
+  uint16_t f = d.flags[vid];
+  if (!(f & VF_PARKED)) { f |= VF_PARKED; atomicAdd((unsigned long long*)&d.cnt->parked, 1ULL); }
+  if (f & VF_TOBLOCK) f = (f & ~VF_TOBLOCK) | VF_SERVICING;
+  d.flags[vid] = f;
+}
+// (schedule slot, rank) of CityBlocks (which = 0, ids = block index) or vehicles (which = 1, ids = vehicle id)
+__global__ void k_gather_ranks(Dev d, const int32_t* ids, int n, int which, int32_t* out) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int slot = which == 0 ? d.bslot[ids[k]] : d.sched_slot[ids[k]];
+  out[2 * k] = slot; out[2 * k + 1] = (int)d.rank[slot];
+}
+// ServiceVehicleAgent._finish_service, device part: _unpark, new target, phase (vehicle_service.py:106-141);
+// _compute_path's cooldown reset (vehicle_base.py:147)
+__global__ void k_svc_finish(Dev d, TsParams P, int vid, int target, int to_block) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint16_t f = d.flags[vid];
+  if (f & VF_PARKED) { f &= ~VF_PARKED; atomicAdd((unsigned long long*)&d.cnt->parked, (unsigned long long)-1LL); }
+  f &= ~(VF_SERVICING | VF_TOBLOCK);
+  if (to_block) f |= VF_TOBLOCK; else f &= ~VF_KEEP;   // remove_on_arrival = True on the way out
+  d.flags[vid] = f;
+  d.target[vid] = target;
+  d.cooldown[vid] = P.pathfinding_cooldown;
+}
+__global__ void k_flags_or(Dev d, int vid, int bits) {
+  if (threadIdx.x || blockIdx.x) return;
+  d.flags[vid] |= (uint16_t)bits;
+}
+
 __global__ void k_rank_invert(const uint32_t* perm, uint32_t* rank, int n) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n) rank[perm[q]] = (uint32_t)q;
@@ -874,6 +932,31 @@ struct ts_engine {
     std::vector<Trip> pending;
     int current_day = 0;
   } gen;
+  // CityBlock food / waste and ServiceVehicleAgent loads: host state, advanced in rank order next to the device's
+  // move phase (city_block.py, vehicle_service.py)
+  struct Block {
+    int cells = 0;
+    bool needs_food = false, produces_waste = false;
+    double max_food = 0, max_waste = 0, food = 0, waste = 0, food_rate = 0, waste_rate = 0, food_rem = 0, waste_rem = 0;
+    int ticks_since_food = 0, ticks_since_waste = 0;
+    std::vector<int> service_cells;
+  };
+  std::vector<Block> blocks;
+  int blocks_scheduled = 0, cap_bslot = 0;
+  struct SvcVeh {
+    int vid, type, id, block;     // type: TS_TRIP_SERVICE_FOOD / _WASTE; id: index into the fleet's id pool
+    double load, max_load;
+    int phase;                    // 0 to_block, 1 servicing, 2 to_exit
+    int ticks;                    // service_ticks
+    int pos;                      // where it parked (valid while servicing)
+    int target;
+  };
+  std::vector<SvcVeh> svc;                      // live service vehicles
+  std::unordered_map<int, int> parked_cells;    // cell -> parked vehicles on it (only service vehicles ever park)
+  std::vector<char> sv_live;                    // ids in the scheduler: [food ids..., waste ids...]
+  int32_t *d_ids = nullptr, *d_sr = nullptr;    // k_gather_ranks staging
+  int cap_ids = 0;
+  int fatal = 0;                                // an exception the reference would have raised inside model.step()
   // device-side RNG bookkeeping
   uint32_t* h_words = nullptr;        // pinned storage of the global stream's tempered-word ring
   uint64_t words_uploaded = 0;        // absolute word index up to which d.words mirrors it
@@ -917,6 +1000,7 @@ struct ts_engine {
 };
 
 static int add_vehicle_planned(ts_handle e, int start, int goal, int pop_type);  // defined with the C-ABI entries
+static int plan_vehicle(ts_handle e, int vid, int start, int goal);
 
 namespace {
 
@@ -1458,10 +1542,27 @@ int rain_agent_step(E* e, int hid) {
   return 0;
 }
 
-// _generate_day (dynamic_traffic_generator.py:307-396), internal + through trips; service quotas must be 0
+// _generate_day (dynamic_traffic_generator.py:307-396): internal, service and through trips of one day
 void generate_day(E* e, int day_idx) {
   auto& G = e->gen;
   MTPipe& r = e->rng_global;
+  // compute_quotas (319-331): floors, then +1 for the largest fractional parts (stable, descending)
+  auto quotas = [&](int total) {
+    const int nz = G.T.n_zones;
+    std::vector<double> fc(nz);
+    std::vector<int> fl(nz), order(nz);
+    long long sum = 0;
+    for (int z = 0; z < nz; z++) {
+      fc[z] = (double)total * G.T.zones[z].through_distribution;
+      fl[z] = (int)std::floor(fc[z]); sum += fl[z]; order[z] = z;
+    }
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int a, int b) { return fc[a] - std::floor(fc[a]) > fc[b] - std::floor(fc[b]); });
+    const long long rem = total - sum;
+    for (long long i = 0; i < rem && i < nz; i++) fl[order[i]] += 1;
+    return fl;
+  };
+  const std::vector<int> food_q = quotas(G.T.total_service_vehicles_food), waste_q = quotas(G.T.total_service_vehicles_waste);
   for (int zi = 0; zi < G.T.n_zones; zi++) {
     const TsTrafficZone& z = G.T.zones[zi];
     const double z0 = (double)((long long)day_idx * 86400 + (long long)z.start_hour * 3600 - G.T.start_offset_seconds);
@@ -1485,7 +1586,20 @@ void generate_day(E* e, int day_idx) {
         G.pending.push_back(ts_engine::Trip{oc, dc, t, TS_POP_INTERNAL});
       }
     }
+    // service vehicles, uniform per zone (362-376): one entrance draw per trip
+    const int Nf = food_q[zi], Nw = waste_q[zi];
+    for (int j = 1; j <= Nf; j++) {
+      const double t = z0 + (double)((long long)j * (long long)span) / (double)(Nf + 1);
+      const int sc = G.hw_in[r.randbelow((uint32_t)G.hw_in.size())];
+      G.pending.push_back(ts_engine::Trip{sc, -1, t, TS_TRIP_SERVICE_FOOD});
+    }
+    for (int j = 1; j <= Nw; j++) {
+      const double t = z0 + (double)((long long)j * (long long)span) / (double)(Nw + 1);
+      const int sc = G.hw_in[r.randbelow((uint32_t)G.hw_in.size())];
+      G.pending.push_back(ts_engine::Trip{sc, -1, t, TS_TRIP_SERVICE_WASTE});
+    }
     long long thr = (long long)std::nearbyint((double)G.T.passing_population_per_day * z.through_distribution);
+    thr -= Nf + Nw;   // SERVICE_VEHICLES_COUNT_AS_THROUGH defaults to True (90, 381-382)
     for (long long q = 0; q < thr; q++) {
       const double t = z0 + r.random() * span;
       const int ent = G.hw_in[r.randbelow((uint32_t)G.hw_in.size())];
@@ -1493,6 +1607,153 @@ void generate_day(E* e, int day_idx) {
       G.pending.push_back(ts_engine::Trip{ent, ex, t, TS_POP_THROUGH});
     }
   }
+}
+
+
+// ------------------------------ city blocks + service vehicles (host state) -------------------------------
+// CityBlock.step (city_block.py:110-150)
+void block_step(E* e, int bi) {
+  if (bi >= (int)e->blocks.size()) return;
+  auto& b = e->blocks[bi];
+  const TsTrafficTables& T = e->gen.T;
+  if (b.needs_food) {
+    if (T.gradual_city_block_resources) {
+      b.food_rem += b.food_rate;
+      if (b.food_rem >= 1.0) { const double whole = std::trunc(b.food_rem); b.food = std::max(b.food - whole, 0.0); b.food_rem -= whole; }
+    } else if (++b.ticks_since_food >= T.food_consumption_ticks) {
+      b.food = std::max(b.food - (double)b.cells, 0.0); b.ticks_since_food = 0;
+    }
+  }
+  if (b.produces_waste) {
+    if (T.gradual_city_block_resources) {
+      b.waste_rem += b.waste_rate;
+      if (b.waste_rem >= 1.0) { const double whole = std::trunc(b.waste_rem); b.waste = std::min(b.waste + whole, b.max_waste); b.waste_rem -= whole; }
+    } else if (++b.ticks_since_waste >= T.waste_production_ticks) {
+      b.waste = std::min(b.waste + (double)b.cells, b.max_waste); b.ticks_since_waste = 0;
+    }
+  }
+}
+
+// CityBlock.get_service_road_cell step 4 (city_block.py:192-202): first ranked cell without a parked vehicle
+int service_road_cell(E* e, int bi) {
+  for (int c : e->blocks[bi].service_cells) {
+    auto it = e->parked_cells.find(c);
+    if (it == e->parked_cells.end() || it->second <= 0) return c;
+  }
+  return -1;
+}
+
+int svc_find(E* e, int vid) {
+  for (size_t k = 0; k < e->svc.size(); k++) if (e->svc[k].vid == vid) return (int)k;
+  return -1;
+}
+
+// ServiceVehicleAgent._start_service, host part (vehicle_service.py:85-104); `pos` = the cell it parked on
+void svc_start(E* e, ts_engine::SvcVeh& v) {
+  if (v.phase != 0 || v.block < 0) {   // a vehicle that merely parks (base on_target_reached with remove_on_arrival False)
+    e->parked_cells[v.target]++;
+    return;
+  }
+  e->parked_cells[v.target]++;
+  v.pos = v.target;
+  auto& b = e->blocks[v.block];
+  if (v.type == TS_TRIP_SERVICE_FOOD) {
+    const double need = b.max_food - b.food;
+    const double amt = std::min(v.load, need);
+    b.food = std::min(b.food + amt, b.max_food);
+    v.load -= amt;
+  } else {
+    const double surplus = b.waste;
+    const double cap = v.max_load - v.load;
+    const double amt = std::min(cap, surplus);
+    b.waste = std::max(b.waste - amt, 0.0);
+    v.load += amt;
+  }
+  v.ticks = e->gen.T.service_load_time;
+  v.phase = 1;
+}
+
+// ServiceVehicleAgent._finish_service (vehicle_service.py:106-141) at the vehicle's place in the shuffled order:
+// every lower-ranked agent has stepped on the device, every higher-ranked one has not
+int svc_finish(E* e, ts_engine::SvcVeh& v) {
+  auto& G = e->gen;
+  { auto it = e->parked_cells.find(v.pos); if (it != e->parked_cells.end() && --it->second <= 0) e->parked_cells.erase(it); }
+  const bool more = v.type == TS_TRIP_SERVICE_FOOD ? v.load > 0 : v.load < v.max_load;
+  int target = -1, to_block = 0;
+  if (more) {
+    int nb = -1;   // get_block_most_in_need_of_food / _waste_pickup (city_model.py:2078-2087): stable sort, first element
+    for (size_t b = 0; b < e->blocks.size(); b++) {
+      const auto& B = e->blocks[b];
+      if (v.type == TS_TRIP_SERVICE_FOOD) { if (B.needs_food && (nb < 0 || B.food < e->blocks[nb].food)) nb = (int)b; }
+      else { if (B.produces_waste && (nb < 0 || B.waste > e->blocks[nb].waste)) nb = (int)b; }
+    }
+    if (nb >= 0) {
+      v.block = nb;
+      target = service_road_cell(e, nb);
+      if (target < 0) {
+        e->fatal = TS_E_UNSUPPORTED;
+        return fail(e, TS_E_UNSUPPORTED, "service vehicle: every service road cell of the next block holds a parked vehicle (the reference raises)");
+      }
+      to_block = 1;
+    }
+  }
+  if (!to_block) {
+    int best_d = 0;
+    for (int c : G.hw_out) {   // min(exits, key=manhattan): first minimum
+      const int dd = std::abs(c % e->W - v.pos % e->W) + std::abs(c / e->W - v.pos / e->W);
+      if (target < 0 || dd < best_d) { target = c; best_d = dd; }
+    }
+    if (target < 0) { e->fatal = TS_E_UNSUPPORTED; return fail(e, TS_E_UNSUPPORTED, "service vehicle without highway exits (the reference raises)"); }
+  }
+  hipLaunchKernelGGL(k_svc_finish, dim3(1), dim3(64), 0, e->stream, e->d, e->P, v.vid, target, to_block);
+  v.target = target;
+  v.phase = to_block ? 0 : 2;
+  return plan_vehicle(e, v.vid, v.pos, target);
+}
+
+// _spawn for service trips (dynamic_traffic_generator.py:419-430) + ServiceVehicleAgent.__init__ (vehicle_service.py:19-41)
+int spawn_service(E* e, const ts_engine::Trip& t) {
+  auto& G = e->gen;
+  const bool food = t.kind == TS_TRIP_SERVICE_FOOD;
+  if (food) e->C.created_service_food++; else e->C.created_service_waste++;
+  const int pool = food ? G.T.total_service_vehicles_food : G.T.total_service_vehicles_waste;
+  const int id = (int)e->rng_global.randbelow((uint32_t)pool);   // vid = random.choice(pool)
+  // _find_initial_target (62-83): `attempt` is never advanced, so only valid_blocks[0] is ever tried
+  int blk = -1;
+  for (size_t b = 0; b < e->blocks.size(); b++)
+    if (food ? e->blocks[b].needs_food : e->blocks[b].produces_waste) { blk = (int)b; break; }
+  int target, phase;
+  if (blk >= 0) {
+    target = service_road_cell(e, blk);
+    if (target < 0) {
+      e->fatal = TS_E_UNSUPPORTED;
+      return fail(e, TS_E_UNSUPPORTED, "service vehicle: no free service road cell at its first block (the reference loops forever)");
+    }
+    phase = 0;
+  } else {
+    if (G.hw_out.empty()) { e->fatal = TS_E_UNSUPPORTED; return fail(e, TS_E_UNSUPPORTED, "service vehicle without highway exits (IndexError in the reference)"); }
+    target = G.hw_out[0];
+    phase = 2;
+  }
+  char& live = e->sv_live[(size_t)(food ? 0 : G.T.total_service_vehicles_food) + id];
+  if (live) {   // BaseScheduler.add raises on a unique_id that is already scheduled (Mesa <= 2.1)
+    e->fatal = TS_E_UNSUPPORTED;
+    return fail(e, TS_E_UNSUPPORTED, "service vehicle id drawn while a vehicle with that id is still live (the scheduler raises in the reference)");
+  }
+  if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
+  int rc = add_vehicle_planned(e, t.origin, target, TS_POP_THROUGH);
+  if (rc) return rc;
+  const int vid = e->n_vehicles_total - 1;
+  hipLaunchKernelGGL(k_flags_or, dim3(1), dim3(64), 0, e->stream, e->d, vid, (int)(VF_SVC | VF_KEEP | (phase == 0 ? VF_TOBLOCK : 0)));
+  live = 1;
+  ts_engine::SvcVeh v;
+  v.vid = vid; v.type = t.kind; v.id = id; v.block = blk;
+  v.max_load = food ? G.T.service_max_load_food : G.T.service_max_load_waste;
+  v.load = food ? v.max_load : 0.0;
+  v.phase = phase; v.ticks = 0; v.pos = t.origin; v.target = target;
+  e->svc.push_back(v);
+  if (food) e->C.live_service_food++; else e->C.live_service_waste++;
+  return TS_OK;
 }
 
 // DynamicTrafficAgent.step (153-194) and _spawn (398-416), executed at the agent's place in the shuffled order:
@@ -1507,11 +1768,17 @@ int generator_step(E* e) {
     for (int dd = G.current_day + 1; dd <= new_day; dd++) generate_day(e, dd);
     G.current_day = new_day;
     e->C.created_internal = 0; e->C.created_through = 0;
+    e->C.created_service_food = 0; e->C.created_service_waste = 0;
   }
   std::vector<ts_engine::Trip> keep, spawn;
   for (const auto& t : G.pending) (prev < t.depart && t.depart <= e->C.elapsed ? spawn : keep).push_back(t);
   G.pending.swap(keep);
   for (const auto& t : spawn) {
+    if (t.kind == TS_TRIP_SERVICE_FOOD || t.kind == TS_TRIP_SERVICE_WASTE) {
+      int rc = spawn_service(e, t);
+      if (rc) return rc;
+      continue;
+    }
     if (t.kind == TS_POP_INTERNAL) e->C.created_internal++; else e->C.created_through++;
     (void)e->rng_global.randint(0, 9999);  // the id suffix of "V_{depart:06d}_{randint(0, 9999):04d}"
     if (t.origin == t.dest) return fail(e, TS_E_UNSUPPORTED, "generated trip with origin == destination");
@@ -1565,6 +1832,22 @@ int tick(E* e) {
   // density_map is a function of the occupancy at this point (city_model.py:1853)
   HIPOK(hipMemcpyAsync(d.occ_snap, d.occ, (size_t)e->N, hipMemcpyDeviceToDevice, st));
   e->density_valid = false;
+  d.elapsed = e->C.elapsed;
+  const bool svc_on = !e->svc.empty();
+  int arr_read = 0;   // service records of this tick consumed so far
+  if (svc_on) HIPOK(hipMemsetAsync(&d.cnt->arr_n, 0, sizeof(int), st));
+  // fetch records [arr_read, upto) from the device
+  std::vector<int32_t> recs;
+  auto fetch_records = [&](int upto) -> int {
+    recs.clear();
+    if (upto > d.arr_cap) return fail(e, TS_E_CAPACITY, "more service records in one tick than the record buffer holds");
+    if (upto <= arr_read) return TS_OK;
+    recs.resize((size_t)(upto - arr_read) * 3);
+    HIPOK(hipMemcpyAsync(recs.data(), d.arr + 3 * (size_t)arr_read, recs.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    arr_read = upto;
+    return TS_OK;
+  };
   // ---------------- decide ----------------
   if (nA > 0) {
     HIPOK(hipMemsetAsync(d.ev, 0, (size_t)e->n_vehicles_total, st));
@@ -1711,6 +1994,22 @@ int tick(E* e) {
     { const double t_wu = now_ms(); int rc = words_upload(e, r.pos() + (uint64_t)nA * 4 + (1u << 16)); if (rc) return rc;
       host_prof(e, PH_WORDS, now_ms() - t_wu, nA); }
     if (e->hint[8] > 0) { int rc = run_replans(e, e->hint[8]); if (rc) return rc; }
+    if (svc_on) {
+      // on_target_reached inside step_decide for vehicles that stay on the grid (vehicle_base.py:657-661): apply the
+      // flag changes now that no decider can see them half-way, then the host part in decide order
+      HIPOK(hipMemcpyAsync(e->hint + 2, &d.cnt->arr_n, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPOK(hipStreamSynchronize(st));
+      const int n_rec = e->hint[2];
+      if (n_rec > 0) {
+        int rc = fetch_records(n_rec);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_decide_arrive, dim3(nblk(n_rec)), dim3(BLK), 0, st, d, n_rec);
+        std::vector<std::pair<int, int>> order;   // (decide index, vehicle)
+        for (int k = 0; k < n_rec; k++) if (recs[3 * k + 2] == AR_DECIDE) order.push_back({recs[3 * k], recs[3 * k + 1]});
+        std::sort(order.begin(), order.end());
+        for (auto& o : order) { int k = svc_find(e, o.second); if (k >= 0) svc_start(e, e->svc[k]); }
+      }
+    }
   }
 
   // ---------------- move (schedule.step) ----------------
@@ -1757,24 +2056,103 @@ int tick(E* e) {
       }
       std::sort(host_events.begin(), host_events.end(), [](const HostEv& a, const HostEv& b) { return a.rank < b.rank; });
     }
-    auto run_host_events = [&](uint32_t lo, uint32_t hi) -> int {   // events with lo <= rank < hi, in rank order
-      for (const HostEv& ev : host_events) {
-        if (ev.rank < lo || ev.rank >= hi) continue;
-        if (ev.hid == 0) { int rc = rain_manager_step(e, discs); if (rc) return rc; }
-        else if (rain_agent_step(e, ev.hid)) {
-          const int8_t dead = K_DEAD;   // schedule.remove(self)
-          HIPOK(hipMemcpyAsync(d.sched_kind + ev.slot, &dead, 1, hipMemcpyHostToDevice, st));
-          HIPOK(hipStreamSynchronize(st));
-          host_deaths++;
+    // CityBlocks step on the host at their ranks; service vehicles whose load timer runs out in this tick do
+    // _finish_service there too (it plans a path on the maps as they are at that point, like the generator's spawns)
+    struct Point { uint32_t rank; int kind; int ref; int slot; };   // kind 0 = the clock agent, 1 = finishing service vehicle
+    std::vector<Point> points;
+    struct StaticEv { uint32_t rank; int kind; int ref; };          // kind 0 = rain event (index), 1 = CityBlock
+    std::vector<StaticEv> static_events;
+    for (size_t k = 0; k < host_events.size(); k++) static_events.push_back(StaticEv{host_events[k].rank, 0, (int)k});
+    if (split) points.push_back(Point{rank_clock, 0, 0, e->clock_slot});
+    {
+      std::vector<int32_t> ids;
+      const int nb = std::min((int)e->blocks.size(), e->blocks_scheduled);
+      for (int b = 0; b < nb; b++) ids.push_back(b);
+      std::vector<int> fin;   // indices into e->svc
+      for (size_t k = 0; k < e->svc.size(); k++) {
+        auto& v = e->svc[k];
+        if (v.phase != 1) continue;
+        if (v.ticks <= 1) { fin.push_back((int)k); ids.push_back(v.vid); }   // service_ticks -= 1; <= 0 -> _finish_service
+        else v.ticks -= 1;
+      }
+      if (!ids.empty()) {
+        if ((int)ids.size() > e->cap_ids) {
+          const int nc = (int)ids.size() * 2 + 64;
+          int rc = regrow(e, &e->d_ids, 0, (size_t)nc); if (rc) return rc;
+          rc = regrow(e, &e->d_sr, 0, (size_t)nc * 2); if (rc) return rc;
+          e->cap_ids = nc;
+        }
+        std::vector<int32_t> sr(ids.size() * 2);
+        HIPOK(hipMemcpyAsync(e->d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
+        if (nb > 0) hipLaunchKernelGGL(k_gather_ranks, dim3(nblk(nb)), dim3(BLK), 0, st, d, e->d_ids, nb, 0, e->d_sr);
+        if (!fin.empty())
+          hipLaunchKernelGGL(k_gather_ranks, dim3(nblk((long long)fin.size())), dim3(BLK), 0, st, d, e->d_ids + nb, (int)fin.size(), 1,
+                             e->d_sr + 2 * nb);
+        HIPOK(hipMemcpyAsync(sr.data(), e->d_sr, sr.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        for (int b = 0; b < nb; b++) static_events.push_back(StaticEv{(uint32_t)sr[2 * b + 1], 1, b});
+        for (size_t q = 0; q < fin.size(); q++)
+          points.push_back(Point{(uint32_t)sr[2 * (nb + q) + 1], 1, e->svc[fin[q]].vid, sr[2 * (nb + q)]});
+      }
+    }
+    std::sort(static_events.begin(), static_events.end(), [](const StaticEv& a, const StaticEv& b) { return a.rank < b.rank; });
+    std::sort(points.begin(), points.end(), [](const Point& a, const Point& b) { return a.rank < b.rank; });
+    size_t se_cur = 0;
+    // host-side work of every agent ranked below `hi`, in rank order: rain, CityBlocks, and what the device reported
+    // about service vehicles (arrivals -> _start_service, despawns)
+    auto run_window = [&](uint32_t hi) -> int {
+      struct Ev { uint32_t rank; int kind; int ref; };   // kind 0 rain, 1 block, 2 service start, 3 service despawn
+      std::vector<Ev> evs;
+      while (se_cur < static_events.size() && static_events[se_cur].rank < hi) {
+        evs.push_back(Ev{static_events[se_cur].rank, static_events[se_cur].kind, static_events[se_cur].ref});
+        se_cur++;
+      }
+      if (svc_on) {
+        const int upto = e->hint[2];
+        int rc = fetch_records(upto);
+        if (rc) return rc;
+        for (size_t k = 0; k + 2 < recs.size(); k += 3) {
+          if (recs[k + 2] == AR_START) evs.push_back(Ev{(uint32_t)recs[k], 2, recs[k + 1]});
+          else if (recs[k + 2] == AR_DESPAWN) evs.push_back(Ev{(uint32_t)recs[k], 3, recs[k + 1]});
+        }
+      }
+      std::stable_sort(evs.begin(), evs.end(), [](const Ev& a, const Ev& b) { return a.rank < b.rank; });
+      if (getenv("TS_DEBUG_EVENTS"))
+        for (const Ev& ev : evs)
+          fprintf(stderr, "[events] tick %lld rank %u kind %d ref %d%s\n", (long long)e->C.step_count, ev.rank, ev.kind, ev.ref,
+                  ev.kind == 0 ? (host_events[ev.ref].hid == 0 ? " (rain manager)" : " (cloud)") : "");
+      for (const Ev& ev : evs) {
+        if (ev.kind == 0) {
+          const HostEv& h = host_events[ev.ref];
+          if (h.hid == 0) { int rc = rain_manager_step(e, discs); if (rc) return rc; }
+          else if (rain_agent_step(e, h.hid)) {
+            const int8_t dead = K_DEAD;   // schedule.remove(self)
+            HIPOK(hipMemcpyAsync(d.sched_kind + h.slot, &dead, 1, hipMemcpyHostToDevice, st));
+            HIPOK(hipStreamSynchronize(st));
+            host_deaths++;
+          }
+        } else if (ev.kind == 1) {
+          block_step(e, ev.ref);
+        } else {
+          const int k = svc_find(e, ev.ref);
+          if (k < 0) continue;
+          if (ev.kind == 2) svc_start(e, e->svc[k]);
+          else {
+            auto& v = e->svc[k];
+            e->sv_live[(size_t)(v.type == TS_TRIP_SERVICE_FOOD ? 0 : e->gen.T.total_service_vehicles_food) + v.id] = 0;
+            if (v.type == TS_TRIP_SERVICE_FOOD) e->C.live_service_food--; else e->C.live_service_waste--;
+            e->svc.erase(e->svc.begin() + k);
+          }
         }
       }
       return TS_OK;
     };
-    { int rc = run_host_events(0, split ? rank_clock : NO_RANK); if (rc) return rc; }
+    e->hint[0] = 0; e->hint[1] = 0; e->hint[2] = arr_read; e->hint[3] = 0;
     int done = 0;
-    for (int part = split ? 0 : 1; part < 2; part++) {
-      const uint32_t rank_limit = part == 0 ? rank_clock : NO_RANK;
-      const int target = part == 0 ? (int)rank_clock : nS;
+    for (size_t pi = 0; pi <= points.size(); pi++) {
+      const bool last = pi == points.size();
+      const uint32_t rank_limit = last ? NO_RANK : points[pi].rank;
+      const int target = last ? nS : (int)points[pi].rank;
       int round_no = 0, pending_bound = nS;
       HIPOK(hipMemsetAsync(d.cnt->pend_n, 0, sizeof(int) * 2, st));
       while (done < target) {
@@ -1804,18 +2182,26 @@ int tick(E* e) {
         done = now;
         pending_bound = std::max(1, target - done);
       }
-      if (part == 0) {
-        // the generator's turn: DynamicTrafficAgent.step on the host, then mark its slot as stepped
-        int rc = generator_step(e);
-        if (rc) return rc;
-        rc = run_host_events(rank_clock + 1, NO_RANK);
-        if (rc) return rc;
+      const int dev_error = e->hint[3], dev_deaths = e->hint[1];
+      { int rc = run_window(last ? NO_RANK : rank_limit); if (rc) return rc; }
+      if (!last) {
+        const Point& pt = points[pi];
+        if (pt.kind == 0) {
+          // the generator's turn: DynamicTrafficAgent.step on the host
+          int rc = generator_step(e);
+          if (rc) return rc;
+        } else {
+          const int k = svc_find(e, pt.ref);
+          if (k >= 0) { int rc = svc_finish(e, e->svc[k]); if (rc) return rc; }
+        }
+        // mark the agent's slot as stepped
         const uint8_t one = 1;
-        HIPOK(hipMemcpyAsync(d.resolved + e->clock_slot, &one, 1, hipMemcpyHostToDevice, st));
+        HIPOK(hipMemcpyAsync(d.resolved + pt.slot, &one, 1, hipMemcpyHostToDevice, st));
         done += 1;
         HIPOK(hipMemcpyAsync(&d.cnt->resolved, &done, sizeof(int), hipMemcpyHostToDevice, st));
         HIPOK(hipStreamSynchronize(st));
       }
+      e->hint[3] = dev_error; e->hint[1] = dev_deaths;
     }
     if (e->hint[3]) return fail(e, e->hint[3], "device-side error: a vehicle sits on its target during decide (start == goal is not supported)");
     if (discs.n >= 0)   // RainManager.step ran: rain_map is exactly the union of the discs it saw
@@ -2037,7 +2423,8 @@ int ts_set_lights(ts_handle e, const TsLightTables* t) {
 
 int ts_schedule_add(ts_handle e, int32_t kind, int32_t count) {
   if (!e || count < 0) return TS_E_INVALID;
-  if (kind != TS_AGENT_LIGHT_GROUP && kind != TS_AGENT_NOOP && kind != TS_AGENT_CLOCK && kind != TS_AGENT_RAIN_MANAGER)
+  if (kind != TS_AGENT_LIGHT_GROUP && kind != TS_AGENT_NOOP && kind != TS_AGENT_CLOCK && kind != TS_AGENT_RAIN_MANAGER &&
+      kind != TS_AGENT_CITY_BLOCK)
     return fail(e, TS_E_INVALID, "bad agent kind");
   if (kind == TS_AGENT_RAIN_MANAGER && (count > 1 || e->rain_manager) && count > 0)
     return fail(e, TS_E_INVALID, "at most one rain manager");
@@ -2053,7 +2440,18 @@ int ts_schedule_add(ts_handle e, int32_t kind, int32_t count) {
   std::vector<int32_t> refs(count, 0), slots(count);
   for (int i = 0; i < count; i++) {
     if (kind == TS_AGENT_LIGHT_GROUP) refs[i] = e->groups_scheduled + i;
+    if (kind == TS_AGENT_CITY_BLOCK) refs[i] = e->blocks_scheduled + i;
     slots[i] = e->n_sched + i;
+  }
+  if (kind == TS_AGENT_CITY_BLOCK) {   // the n-th CityBlock scheduled is block n of city_blocks (city_model.py:1738)
+    if (e->blocks_scheduled + count > e->cap_bslot) {
+      const int nc = (e->blocks_scheduled + count) * 2 + 64;
+      rc = regrow(e, &e->d.bslot, (size_t)e->blocks_scheduled, (size_t)nc);
+      if (rc) return rc;
+      e->cap_bslot = nc;
+    }
+    HIPOK(hipMemcpy(e->d.bslot + e->blocks_scheduled, slots.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+    e->blocks_scheduled += count;
   }
   HIPOK(hipMemcpy(e->d.sched_kind + e->n_sched, kinds.data(), count, hipMemcpyHostToDevice));
   HIPOK(hipMemcpy(e->d.sched_ref + e->n_sched, refs.data(), (size_t)count * 4, hipMemcpyHostToDevice));
@@ -2100,6 +2498,37 @@ int ts_set_traffic_generator(ts_handle e, const TsTrafficTables* t) {
   if ((G.hw_in.empty() || G.hw_out.empty()) && t->passing_population_per_day > 0)
     return fail(e, TS_E_UNSUPPORTED, "through traffic needs highway entrances and exits");
   for (int z = 0; z < t->n_zones; z++) if (t->zones[z].n_internal < 0 || t->zones[z].n_internal > 8) return TS_E_INVALID;
+  e->blocks.clear();
+  if (t->blk_inner_cells) {
+    if (!t->blk_service_off || !t->blk_service_xy) return fail(e, TS_E_INVALID, "blk_service_* tables missing");
+    e->blocks.resize(t->n_blocks);
+    for (int b = 0; b < t->n_blocks; b++) {
+      auto& B = e->blocks[b];
+      B.cells = t->blk_inner_cells[b];
+      B.needs_food = (t->needs_food_type_mask >> t->blk_type[b]) & 1;
+      B.produces_waste = (t->produces_waste_type_mask >> t->blk_type[b]) & 1;
+      B.max_food = (double)B.cells * t->food_capacity_per_cell;
+      B.max_waste = (double)B.cells * t->waste_capacity_per_cell;
+      B.food = B.max_food; B.waste = 0.0;
+      B.food_rate = (double)B.cells / (double)t->food_consumption_ticks;
+      B.waste_rate = (double)B.cells / (double)t->waste_production_ticks;
+      for (int k = t->blk_service_off[b]; k < t->blk_service_off[b + 1]; k++) {
+        int c;
+        if (!cellxy(t->blk_service_xy, k, c)) return fail(e, TS_E_INVALID, "service road cell out of bounds");
+        B.service_cells.push_back(c);
+      }
+    }
+  }
+  const int n_sv = t->total_service_vehicles_food + t->total_service_vehicles_waste;
+  if (n_sv < 0 || t->total_service_vehicles_food < 0 || t->total_service_vehicles_waste < 0) return TS_E_INVALID;
+  if (n_sv > 0 && (e->blocks.empty() || G.hw_in.empty()))
+    return fail(e, TS_E_UNSUPPORTED, "service vehicles need the block tables and highway entrances");
+  e->sv_live.assign((size_t)n_sv, 0);
+  e->svc.clear(); e->parked_cells.clear();
+  if (n_sv > 0 && !e->d.arr) {
+    e->d.arr_cap = 1 << 16;
+    HIPOK(dalloc(e, &e->d.arr, (size_t)e->d.arr_cap * 3));
+  }
   G.pending.clear();
   G.current_day = 0;
   G.armed = true;
@@ -2203,7 +2632,13 @@ static int add_vehicle_planned(ts_handle e, int start, int goal, int pop_type) {
   std::vector<uint32_t> o1{0}, enc;
   int rc = add_vehicles_core(e, 1, s1, g1, p1, l1, o1, enc);
   if (rc) return rc;
-  const int vid = e->n_vehicles_total - 1;
+  return plan_vehicle(e, e->n_vehicles_total - 1, start, goal);
+}
+
+// self.path = self._compute_path() for a vehicle standing on `start` with target `goal` (both already on the
+// device): city._path_cache first, then the phase 0-4 planner on the maps as they are now
+static int plan_vehicle(ts_handle e, int vid, int start, int goal) {
+  int rc;
   const uint64_t key = ((uint64_t)(uint32_t)start << 32) | (uint32_t)goal;
   Dev& d = e->d;
   if (e->P.pathfinding_cache) {
@@ -2349,6 +2784,7 @@ int ts_step(ts_handle e, int32_t n_ticks) {
   if (!e->rng_global.seeded() || !e->rng_sched.seeded()) return fail(e, TS_E_STATE, "both RNG streams must be seeded before step");
   if (e->groups_scheduled != e->d.G && e->d.G > 0 && e->groups_scheduled != 0)
     return fail(e, TS_E_STATE, "every light group must be scheduled (or none)");
+  if (e->fatal) return e->fatal;   // model.step() raised in the reference: the run is over
   for (int t = 0; t < n_ticks; t++) {
     int rc = tick(e);
     if (rc) return rc;
@@ -2429,6 +2865,12 @@ int ts_download_groups(ts_handle e, int32_t* rows) {
   return G;
 }
 
+int ts_num_blocks(ts_handle e) { return e ? (int)e->blocks.size() : TS_E_INVALID; }
+int ts_download_blocks(ts_handle e, double* rows) {
+  if (!e || !rows) return TS_E_INVALID;
+  for (size_t b = 0; b < e->blocks.size(); b++) { rows[2 * b] = e->blocks[b].food; rows[2 * b + 1] = e->blocks[b].waste; }
+  return TS_OK;
+}
 int ts_counters(ts_handle e, TsCounters* out) {
   if (!e || !out) return TS_E_INVALID;
   int rc = sync_counters(e);

@@ -10,7 +10,7 @@ import numpy as np
 from . import _capi as capi
 
 # schedule_kinds0 codes written by tests/golden/make_golden.py::world_tables
-_KIND_TO_AGENT = {0: capi.AGENT_LIGHT_GROUP, 1: capi.AGENT_NOOP, 2: capi.AGENT_RAIN_MANAGER, 3: capi.AGENT_CLOCK,
+_KIND_TO_AGENT = {0: capi.AGENT_LIGHT_GROUP, 1: capi.AGENT_CITY_BLOCK, 2: capi.AGENT_RAIN_MANAGER, 3: capi.AGENT_CLOCK,
                   4: capi.AGENT_NOOP}
 
 
