@@ -321,6 +321,19 @@ int ts_num_scheduled(ts_handle h); /* len(schedule._agents) */
 int ts_download_map(ts_handle h, int32_t which, int8_t* dst);
 int ts_download_density(ts_handle h, float* dst); /* _update_density_map (1764-1778), recomputed now */
 int ts_download_vehicles(ts_handle h, int32_t* rows, int32_t cap_rows); /* [n][TS_V_NFIELDS] */
+/* What a vehicle *is* (constant or slowly changing; vehicle_base.py:29-40, vehicle_service.py:27-41), one row per live
+ * vehicle in the order of ts_download_vehicles: what the UI needs for vehicles the traffic generator created. */
+enum {
+  TS_M_SPAWN_IDX = 0, TS_M_POPULATION /* TS_POP_* */, TS_M_TARGET_X, TS_M_TARGET_Y,
+  TS_M_VEHICLE_TYPE /* 0 plain, TS_TRIP_SERVICE_FOOD, TS_TRIP_SERVICE_WASTE */,
+  TS_M_SERVICE_PHASE /* -1 none, 0 "to_block", 1 "servicing", 2 "to_exit" */,
+  TS_M_NFIELDS
+};
+int ts_num_spawned(ts_handle h); /* vehicles ever placed = the next spawn index (ts_add_vehicles and the generator share it) */
+int ts_download_vehicle_meta(ts_handle h, int32_t* rows, int32_t cap_rows); /* [n][TS_M_NFIELDS], returns n */
+/* ServiceVehicleAgent.current_load / max_load / current_block of every live service vehicle; returns their number.
+ * spawn_idx [n], loads [n][2], block [n] (index into city_blocks, -1 = None) */
+int ts_download_service_vehicles(ts_handle h, int32_t* spawn_idx, double* loads, int32_t* block, int32_t cap);
 /* remaining path of the vehicle at position `active_pos`; returns its length (cells). */
 int ts_download_path(ts_handle h, int32_t active_pos, int32_t* xy, int32_t cap_cells);
 int ts_download_groups(ts_handle h, int32_t* rows); /* [G][TS_G_NFIELDS] */

@@ -1712,6 +1712,34 @@ int tso_download_vehicles(ts_handle e, int32_t* rows, int32_t cap_rows) {
   return n;
 }
 
+int tso_num_spawned(ts_handle e) { return e ? (int)e->veh.size() : TS_E_INVALID; }
+int tso_download_vehicle_meta(ts_handle e, int32_t* rows, int32_t cap_rows) {
+  if (!e || !rows) return TS_E_INVALID;
+  int n = 0;
+  for (int vid : e->active) {
+    if (vid < 0) continue;
+    if (n >= cap_rows) return TS_E_CAPACITY;
+    const Vehicle& v = e->veh[vid];
+    int32_t* r = rows + (size_t)n * TS_M_NFIELDS;
+    r[TS_M_SPAWN_IDX] = v.spawn_idx; r[TS_M_POPULATION] = v.pop_type;
+    r[TS_M_TARGET_X] = v.target % e->W; r[TS_M_TARGET_Y] = v.target / e->W;
+    r[TS_M_VEHICLE_TYPE] = v.svc_type; r[TS_M_SERVICE_PHASE] = v.svc_type ? v.svc_phase : -1;
+    n++;
+  }
+  return n;
+}
+int tso_download_service_vehicles(ts_handle e, int32_t* spawn_idx, double* loads, int32_t* block, int32_t cap) {
+  if (!e || !spawn_idx || !loads || !block) return TS_E_INVALID;
+  int n = 0;
+  for (int vid : e->active) {
+    if (vid < 0 || !e->veh[vid].svc_type) continue;
+    if (n >= cap) return TS_E_CAPACITY;
+    const Vehicle& v = e->veh[vid];
+    spawn_idx[n] = v.spawn_idx; loads[2 * n] = v.current_load; loads[2 * n + 1] = v.max_load; block[n] = v.current_block;
+    n++;
+  }
+  return n;
+}
 int tso_download_path(ts_handle e, int32_t active_pos, int32_t* xy, int32_t cap_cells) {
   if (!e) return TS_E_INVALID;
   int n = 0;

@@ -151,3 +151,10 @@ def test_facade_on_hip(hip):
     """The Mesa-shaped facade (CityModel / VehicleAgent / grid / schedule) over the HIP engine."""
     from tests.test_mesa_facade import run_facade_against_trace
     run_facade_against_trace(hip)
+
+
+def test_facade_with_generator_on_hip(hip):
+    """The same facade with the engine's traffic generator armed: generator-spawned vehicles, service vehicles and
+    CityBlock views read from the HIP engine."""
+    from tests.test_mesa_facade import run_facade_with_generator
+    run_facade_with_generator(hip)

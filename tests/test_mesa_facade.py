@@ -68,3 +68,46 @@ def run_facade_against_trace(engine, name="lights_qa_96_s2", ticks=30):
 
 def test_facade_over_oracle(oracle):
     run_facade_against_trace(oracle)
+
+
+def run_facade_with_generator(engine, name="service_64_s15", ticks=420):
+    """The engine's traffic generator behind the facade: vehicles it spawns appear as views, service vehicles carry
+    their load / block / phase, CityBlock views read the stock (vehicle_service.py, city_block.py, city_model.py:1738)."""
+    import json
+    tr = load_trace(trace_path(name))
+    dta = json.loads(str(tr["dta_params"]))
+    m = CityModel.from_tables(tr, seed=1, defaults=tr["defaults_json"], engine=engine, traffic=dta,
+                              global_state=tr["global_rng_before_day0"], sched_state=tr["sched_rng_initial"])
+    for i, (s, g) in enumerate(zip(tr["v_start_xy"], tr["v_goal_xy"])):
+        VehicleAgent(f"gv_{i}", m, m.cell(int(s[0]), int(s[1])), m.cell(int(g[0]), int(g[1])), population_type="through")
+    assert len(m.city_blocks) == len(tr["blk_type"])
+    fields = tr["cnt_fields"]
+    seen_service = set()
+    for t in range(ticks):
+        m.step()
+        want = tr["veh_rows"][tr["veh_off"][t]:tr["veh_off"][t + 1]]
+        live = m.active_vehicle_agents
+        assert [v._spawn_idx for v in live] == list(want[:, 0])
+        for v in live:
+            if v.vehicle_type in ("food", "waste"):
+                seen_service.add(v._spawn_idx)
+                assert v.population_type == "through" and v.phase in ("to_block", "servicing", "to_exit")
+                assert 0.0 <= v.current_load <= v.max_load
+                assert (v.phase == "servicing") <= v.is_parked
+                assert v.get_portrayal()["Type"].endswith("ServiceVehicle")
+        got = np.asarray([[b.get_food_units(), b.get_waste_units()] for b in m.city_blocks.values()])
+        assert np.array_equal(got, tr["blk_rows"][t])
+    stats = m.dynamic_traffic_generator.cached_stats
+    want_c = dict(zip(fields, tr["cnt_rows"][ticks - 1]))
+    for k in ("created_service_food", "created_service_waste", "live_service_food", "live_service_waste", "live_through", "parked"):
+        assert stats[k] == want_c[k], k
+    assert seen_service, "the scenario is expected to spawn service vehicles"
+    # a vehicle added through the facade after engine-side spawns gets the next free spawn index
+    v = VehicleAgent("late_one", m, m.cell(*map(int, tr["v_start_xy"][0])), m.cell(*map(int, tr["v_goal_xy"][0])))
+    assert v._spawn_idx == m.engine.num_spawned() - 1 and v in m.active_vehicle_agents
+    assert len(m.schedule.agents) == len(m.intersection_light_groups) + len(m.city_blocks) + 1 + len(m.active_vehicle_agents)
+    return m
+
+
+def test_facade_with_generator_over_oracle(oracle):
+    run_facade_with_generator(oracle)

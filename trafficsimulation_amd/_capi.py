@@ -19,6 +19,8 @@ LIGHT_ALGORITHMS = {
     "DISABLED": 0, "FIXED_TIME": 1, "QUEUE_ACTUATED": 2, "PRESSURE_CONTROL": 3,
     "NEIGHBOR_PRESSURE_CONTROL": 4, "NEIGHBOR_GREEN_WAVE": 5,
 }
+M_FIELDS = ["spawn_idx", "population", "target_x", "target_y", "vehicle_type", "service_phase"]
+TRIP_SERVICE_FOOD, TRIP_SERVICE_WASTE = 3, 4
 AGENT_LIGHT_GROUP, AGENT_NOOP, AGENT_RAIN_MANAGER, AGENT_CLOCK, AGENT_CITY_BLOCK = 0, 1, 2, 3, 6
 MAP_OCCUPANCY, MAP_STOP, MAP_STUCK, MAP_RAIN = 0, 1, 2, 3
 RNG_GLOBAL, RNG_SCHEDULER = 0, 1
@@ -194,7 +196,7 @@ class CApi:
         f("default_params").restype = None
         f("last_error").restype = C.c_char_p
         f("last_error").argtypes = [C.c_void_p]
-        for name in ("destroy", "num_vehicles", "num_groups", "num_scheduled", "num_blocks"):
+        for name in ("destroy", "num_vehicles", "num_groups", "num_scheduled", "num_blocks", "num_spawned"):
             f(name).argtypes = [C.c_void_p]
         f("create").argtypes = [C.POINTER(TsWorld), C.POINTER(TsParams), C.POINTER(C.c_void_p)]
         f("set_lights").argtypes = [C.c_void_p, C.POINTER(TsLightTables)]
@@ -213,6 +215,8 @@ class CApi:
         f("download_path").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         f("download_groups").argtypes = [C.c_void_p, C.c_void_p]
         f("download_blocks").argtypes = [C.c_void_p, C.c_void_p]
+        f("download_vehicle_meta").argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        f("download_service_vehicles").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         f("counters").argtypes = [C.c_void_p, C.POINTER(TsCounters)]
         f("astar").argtypes = [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p, C.c_int32]
         f("debug_set_occupancy").argtypes = [C.c_void_p, C.c_void_p]
@@ -454,6 +458,25 @@ class CApi:
         out = np.zeros((max(n, 1), len(G_FIELDS)), dtype=np.int32)
         self._chk(self._f("download_groups")(self.h, out.ctypes.data))
         return out[:n]
+
+    def num_spawned(self) -> int:
+        return self._chk(self._f("num_spawned")(self.h))
+
+    def vehicle_meta(self) -> np.ndarray:
+        """[n][M_FIELDS] rows in the order of vehicles(): population, target, vehicle type, service phase."""
+        n = self.num_vehicles()
+        out = np.zeros((max(n, 1), len(M_FIELDS)), dtype=np.int32)
+        got = self._chk(self._f("download_vehicle_meta")(self.h, out.ctypes.data, max(n, 1)))
+        return out[:got]
+
+    def service_vehicles(self):
+        """(spawn_idx [n], loads [n][2] = current / max, block [n]) of the live service vehicles, by spawn index."""
+        cap = max(self.num_vehicles(), 1)
+        idx = np.zeros(cap, dtype=np.int32)
+        loads = np.zeros((cap, 2), dtype=np.float64)
+        blk = np.zeros(cap, dtype=np.int32)
+        n = self._chk(self._f("download_service_vehicles")(self.h, idx.ctypes.data, loads.ctypes.data, blk.ctypes.data, cap))
+        return idx[:n], loads[:n], blk[:n]
 
     def num_blocks(self) -> int:
         return self._chk(self._f("num_blocks")(self.h))

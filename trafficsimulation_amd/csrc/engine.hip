@@ -638,6 +638,18 @@ __global__ void k_rows(Dev d, int n_active, const uint32_t* crc_table, int32_t* 
   r[TS_V_PATH_CRC] = (int32_t)crc;
   r[TS_V_OVERTAKE_DUR] = d.over_dur[vid]; r[TS_V_DETOUR_DUR] = d.det_dur[vid];
 }
+__global__ void k_meta_rows(Dev d, int n_active, int32_t* rows) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_active) return;
+  const int vid = d.active[i];
+  int32_t* r = rows + (size_t)i * TS_M_NFIELDS;
+  const int tgt = d.target[vid];
+  const uint16_t f = d.flags[vid];
+  r[TS_M_SPAWN_IDX] = vid; r[TS_M_POPULATION] = d.pop[vid]; r[TS_M_TARGET_X] = tgt % d.W; r[TS_M_TARGET_Y] = tgt / d.W;
+  r[TS_M_VEHICLE_TYPE] = 0;   // the fleet (food / waste) is host state: filled in by ts_download_vehicle_meta
+  r[TS_M_SERVICE_PHASE] = !(f & VF_SVC) ? -1 : (f & VF_TOBLOCK) ? 0 : (f & VF_SERVICING) ? 1 : 2;
+}
+
 __global__ void k_path_cells(Dev d, int vid, int32_t* xy) {
   if (threadIdx.x || blockIdx.x) return;
   int pcur = d.path_cur[vid], plen = d.path_len[vid] - pcur, c = d.pos[vid];
@@ -2833,6 +2845,41 @@ int ts_download_vehicles(ts_handle e, int32_t* rows, int32_t cap_rows) {
   return n;
 }
 
+int ts_num_spawned(ts_handle e) { return e ? e->n_vehicles_total : TS_E_INVALID; }
+int ts_download_vehicle_meta(ts_handle e, int32_t* rows, int32_t cap_rows) {
+  if (!e || !rows) return TS_E_INVALID;
+  const int n = e->n_active;
+  if (n > cap_rows) return TS_E_CAPACITY;
+  if (n == 0) return 0;
+  int32_t* drows = nullptr;
+  HIPOK(hipMalloc((void**)&drows, (size_t)n * TS_M_NFIELDS * 4));
+  hipLaunchKernelGGL(k_meta_rows, dim3(nblk(n)), dim3(BLK), 0, e->stream, e->d, n, drows);
+  HIPOK(hipMemcpyAsync(rows, drows, (size_t)n * TS_M_NFIELDS * 4, hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  (void)hipFree(drows);
+  if (!e->svc.empty()) {
+    std::unordered_map<int, int> type_of;
+    for (const auto& v : e->svc) type_of[v.vid] = v.type;
+    for (int i = 0; i < n; i++) {
+      int32_t* r = rows + (size_t)i * TS_M_NFIELDS;
+      if (r[TS_M_SERVICE_PHASE] >= 0) { auto it = type_of.find(r[TS_M_SPAWN_IDX]); if (it != type_of.end()) r[TS_M_VEHICLE_TYPE] = it->second; }
+    }
+  }
+  return n;
+}
+int ts_download_service_vehicles(ts_handle e, int32_t* spawn_idx, double* loads, int32_t* block, int32_t cap) {
+  if (!e || !spawn_idx || !loads || !block) return TS_E_INVALID;
+  if ((int)e->svc.size() > cap) return TS_E_CAPACITY;
+  std::vector<const ts_engine::SvcVeh*> order;
+  for (const auto& v : e->svc) order.push_back(&v);
+  std::sort(order.begin(), order.end(), [](const ts_engine::SvcVeh* a, const ts_engine::SvcVeh* b) { return a->vid < b->vid; });
+  int n = 0;
+  for (const auto* v : order) {
+    spawn_idx[n] = v->vid; loads[2 * n] = v->load; loads[2 * n + 1] = v->max_load; block[n] = v->block;
+    n++;
+  }
+  return n;
+}
 int ts_download_path(ts_handle e, int32_t active_pos, int32_t* xy, int32_t cap_cells) {
   if (!e || active_pos < 0 || active_pos >= e->n_active) return TS_E_INVALID;
   int vid, cur, len;
