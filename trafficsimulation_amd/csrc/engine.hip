@@ -984,10 +984,16 @@ struct ts_engine {
   uint8_t *d_take = nullptr, *h_take = nullptr;   // take table of the stream range the next pass will walk
   size_t cap_take = 0;
   uint64_t take_guess = 0;
-  std::thread sh_thread;
+  std::thread sh_thread, sh2_thread;
+  std::atomic<int> sh_progress{0};   // draws extracted so far (shuffle pipeline)
+  unsigned sh_gen = 0;
+  int sh_err = 0;
+  int device = 0;
+  hipStream_t perm_stream = nullptr;
+  hipEvent_t perm_ev = nullptr;
   std::mutex sh_mu;
   std::condition_variable sh_cv;
-  bool sh_req = false, sh_done = true, sh_quit = false;
+  bool sh_done = true, sh_quit = false;
   int sh_n = 0;
   std::vector<void*> allocs;
   // per-kernel HIP-event timing (ts_profile_*)
@@ -1143,6 +1149,7 @@ int ensure_vehicle_capacity(E* e, int need_v, int need_sched) {
     int nc = std::max(need_host, e->cap_host * 2 + 1024);
     if (e->hF) (void)hipHostFree(e->hF);
     if (e->hR) (void)hipHostFree(e->hR);
+    if (e->perm_stream) HIPOK(hipStreamSynchronize(e->perm_stream));   // a copy out of hrank may still be in flight
     if (e->hrank) (void)hipHostFree(e->hrank);
     HIPOK(hipHostMalloc((void**)&e->hF, nc));
     HIPOK(hipHostMalloc((void**)&e->hR, nc));
@@ -1354,83 +1361,107 @@ int run_replans(E* e, int n0) {
   return TS_OK;
 }
 
-// random.shuffle(keys) with model.random: Fisher-Yates from the top with _randbelow's
-// rejection sampling, reading pre-generated words.  Leaves perm[q] = schedule slot stepping at time q in the
-// pinned buffer e->hrank (inverted to rank[slot] on the device) and the clock agent's rank in rank_clock_host.
-void shuffle_ranks(E* e, int n) {
+// random.shuffle(keys) with model.random: Fisher-Yates from the top with _randbelow's rejection
+// sampling, reading pre-generated words.  Two persistent threads form a pipeline: the first extracts the draws
+// (they depend only on the word stream and on n), the second applies the swaps a chunk behind it, copies every
+// finished stretch of the permutation (position i is final once element i has been swapped) into the pinned
+// buffer e->hrank and sends it to the device on its own stream.  Result: d_perm[q] = schedule slot stepping at
+// time q (inverted to rank[slot] by k_rank_invert), the clock agent's rank in rank_clock_host.
+constexpr int SH_CH = 1 << 12;
+void shuffle_draws(E* e, int n) {
+  if ((int)e->shuffle_j.size() < n + 64) e->shuffle_j.resize((size_t)n + 64);
+  uint32_t* jb = e->shuffle_j.data();   // jb[(n - 1) - i] = draw of element i
+  MTPipe& r = e->rng_sched;
+  uint64_t w = r.pos();
+  uint32_t cnt = 0;
+  for (int hi = n - 1; hi >= 1; hi -= SH_CH) {
+    const int lo = std::max(1, hi - SH_CH + 1);
+    r.need((uint64_t)(hi - lo + 1) * 4 + 512 + (w - r.pos()));
+    uint64_t limit = w + (uint64_t)(hi - lo + 1) * 4 + 256;
+    // Walk the WORDS in order (addresses are not data dependent, so the loads pipeline): a word is the draw of the
+    // current element if it is below i + 1, otherwise it is a rejected try.  The only loop-carried state is the
+    // element counter.
+    uint32_t nn = (uint32_t)hi + 1;             // i + 1 of the element being drawn
+    const uint32_t nn_end = (uint32_t)lo;       // stop once nn == lo  (element lo - 1 is not ours)
+    while (nn > nn_end) {
+      const int shift = __builtin_clz(nn);      // 32 - bit_length(nn); constant while nn >= 2^(k-1)
+      const uint32_t band_end = std::max(nn_end, (1u << (31 - shift)) - 1u);  // last nn of this band, exclusive
+      while (nn > band_end) {
+        if (w + 256 >= limit) { r.advance_to(w); r.need(8192); limit = w + 8192 - 256; }
+        int burst = 64;   // a short unrolled burst; bounds: at most 64 elements / words per burst
+        while (burst-- > 0 && nn > band_end) {
+          const uint32_t c = r.at(w++) >> shift;
+          const uint32_t acc = c < nn;
+          jb[cnt] = c;
+          cnt += acc;
+          nn -= acc;
+        }
+      }
+    }
+    r.advance_to(w);
+    e->sh_progress.store((int)cnt, std::memory_order_release);
+  }
+}
+void shuffle_swaps(E* e, int n) {
   e->perm.resize(n);
   uint32_t* p = e->perm.data();  // ordinary cached memory, first touched by this thread
   for (int i = 0; i < n; i++) p[i] = (uint32_t)i;
-  MTPipe& r = e->rng_sched;
-  uint64_t w = r.pos();
   const uint32_t cs = e->clock_slot >= 0 ? (uint32_t)e->clock_slot : 0xFFFFFFFFu;
   uint32_t cpos = cs;
-  const int CH = 1 << 12;
-  e->shuffle_j.resize(CH);
-  uint32_t* jb = e->shuffle_j.data();
-  for (int hi = n - 1; hi >= 1; hi -= CH) {
-    const int lo = std::max(1, hi - CH + 1);
-    r.need((uint64_t)(hi - lo + 1) * 4 + 512 + (w - r.pos()));
-    uint64_t limit = w + (uint64_t)(hi - lo + 1) * 4 + 256;
-    // pass A: the draws depend only on the word stream.  Walk the WORDS in order (addresses are not data
-    // dependent, so the loads pipeline): a word is the draw of the current element if it is below i + 1,
-    // otherwise it is a rejected try.  The only loop-carried state is the element counter.
-    {
-      uint32_t nn = (uint32_t)hi + 1;             // i + 1 of the element being drawn
-      const uint32_t nn_end = (uint32_t)lo;       // stop once nn == lo  (element lo - 1 is not ours)
-      uint32_t cnt = 0;
-      while (nn > nn_end) {
-        const int shift = __builtin_clz(nn);      // 32 - bit_length(nn); constant while nn >= 2^(k-1)
-        const uint32_t band_end = std::max(nn_end, (1u << (31 - shift)) - 1u);  // last nn of this band, exclusive
-        while (nn > band_end) {
-          if (w + 256 >= limit) { r.advance_to(w); r.need(8192); limit = w + 8192 - 256; }
-          // a short unrolled burst; bounds: at most 64 elements / words per burst
-          int burst = 64;
-          while (burst-- > 0 && nn > band_end) {
-            const uint32_t c = r.at(w++) >> shift;
-            const uint32_t acc = c < nn;
-            jb[cnt] = c;
-            cnt += acc;
-            nn -= acc;
-          }
-        }
-      }
-      for (uint32_t q = 0; q < cnt; q++) __builtin_prefetch(&p[jb[q]], 1, 1);
-    }
-    // pass B: the swaps, with their targets already on the way
-    for (int i = hi; i >= lo; i--) {
-      const uint32_t j = jb[hi - i];
+  const int total = std::max(0, n - 1);
+  int done = 0, sent_hi = n;   // positions [sent_hi, n) are already on their way to the device
+  auto send = [&](int lo) {    // positions [lo, sent_hi) are final
+    if (lo >= sent_hi) return;
+    memcpy(e->hrank + lo, p + lo, (size_t)(sent_hi - lo) * 4);
+    if (hipMemcpyAsync(e->d_perm + lo, e->hrank + lo, (size_t)(sent_hi - lo) * 4, hipMemcpyHostToDevice, e->perm_stream) != hipSuccess)
+      e->sh_err = 1;
+    sent_hi = lo;
+  };
+  while (done < total) {
+    const int avail = e->sh_progress.load(std::memory_order_acquire);
+    if (avail <= done) { std::this_thread::yield(); continue; }
+    const int m = std::min(avail - done, SH_CH);
+    const uint32_t* jb = e->shuffle_j.data() + done;
+    for (int q = 0; q < m; q++) __builtin_prefetch(&p[jb[q]], 1, 1);
+    const int hi = n - 1 - done;
+    for (int q = 0; q < m; q++) {
+      const int i = hi - q;
+      const uint32_t j = jb[q];
       const uint32_t a = p[i], b = p[j];
       p[i] = b; p[j] = a;
       if (a == cs) cpos = j; else if (b == cs) cpos = (uint32_t)i;
     }
-    r.advance_to(w);
+    done += m;
+    if (sent_hi - (n - done) >= (1 << 18)) send(n - done);
   }
-  memcpy(e->hrank, p, (size_t)n * 4);
+  send(0);
+  if (hipEventRecord(e->perm_ev, e->perm_stream) != hipSuccess) e->sh_err = 1;
   e->rank_clock_host = cs == 0xFFFFFFFFu ? 0xFFFFFFFFu : cpos;
 }
 
-// persistent worker for the scheduler shuffle (a fresh std::thread per tick costs ~50 us and loses locality)
-void shuffle_worker(E* e) {
+// persistent workers for the scheduler shuffle (fresh std::threads per tick cost ~50 us each and lose locality)
+void shuffle_worker(E* e, int role) {
+  if (role == 1) (void)hipSetDevice(e->device);
   std::unique_lock<std::mutex> lk(e->sh_mu);
+  unsigned seen = 0;
   for (;;) {
-    e->sh_cv.wait(lk, [e]() { return e->sh_req || e->sh_quit; });
+    e->sh_cv.wait(lk, [&]() { return e->sh_gen != seen || e->sh_quit; });
     if (e->sh_quit) return;
+    seen = e->sh_gen;
     const int n = e->sh_n;
-    e->sh_req = false;
     lk.unlock();
-    double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    shuffle_ranks(e, n);
-    e->shuffle_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+    const double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (role == 0) shuffle_draws(e, n); else shuffle_swaps(e, n);
+    const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
     lk.lock();
-    e->sh_done = true;
-    e->sh_cv.notify_all();
+    if (role == 1) { e->shuffle_ms = dt; e->sh_done = true; e->sh_cv.notify_all(); }
   }
 }
 void shuffle_start(E* e, int n) {
-  if (!e->sh_thread.joinable()) e->sh_thread = std::thread(shuffle_worker, e);
+  if (!e->sh_thread.joinable()) { e->sh_thread = std::thread(shuffle_worker, e, 0); e->sh2_thread = std::thread(shuffle_worker, e, 1); }
   std::lock_guard<std::mutex> lk(e->sh_mu);
-  e->sh_n = n; e->sh_done = false; e->sh_req = true;
+  e->sh_progress.store(0, std::memory_order_relaxed);
+  e->sh_n = n; e->sh_done = false; e->sh_gen++;
   e->sh_cv.notify_all();
 }
 void shuffle_wait(E* e) {
@@ -1925,7 +1956,27 @@ int tick(E* e) {
       Tcum[0] = 0;
       {
         uint64_t T = 0, ensured = 0;
-        for (int k = 0; k < cnt; k++) {
+        int k0 = 0;
+        {
+          // fast path while the walk stays inside the device-built table: nothing but the dependent chain
+          // T -> address -> byte load -> T (32-bit arithmetic, four rolls per trip)
+          uint32_t T32 = 0;
+          const uint32_t lim = (uint32_t)std::min<size_t>(n_take, 0x7FFFFFFFu);
+          int k = 0;
+          for (; k + 4 <= cnt; k += 4) {
+            const uint32_t r0 = rollD[k], r1 = rollD[k + 1], r2 = rollD[k + 2], r3 = rollD[k + 3];
+            if ((uint64_t)r3 + T32 + 256 >= lim) break;
+            const uint32_t t0 = take_tab[r0 + T32]; const uint32_t a0 = T32 + t0;
+            const uint32_t t1 = take_tab[r1 + a0]; const uint32_t a1 = a0 + t1;
+            const uint32_t t2 = take_tab[r2 + a1]; const uint32_t a2 = a1 + t2;
+            const uint32_t t3 = take_tab[r3 + a2]; const uint32_t a3 = a2 + t3;
+            if (__builtin_expect((t0 == 0) | (t1 == 0) | (t2 == 0) | (t3 == 0), 0)) break;   // a run the table does not record
+            Tcum[k + 1] = a0; Tcum[k + 2] = a1; Tcum[k + 3] = a2; Tcum[k + 4] = a3;
+            T32 = a3;
+          }
+          k0 = k; T = T32;
+        }
+        for (int k = k0; k < cnt; k++) {
           const uint64_t pos = base + rollD[k] + T;
           if (__builtin_expect(pos + 8 >= ensured, 0)) {
             const uint64_t want = (pos - r.pos()) + (1u << 18);
@@ -2036,7 +2087,8 @@ int tick(E* e) {
   const int sched_vehicles_at_shuffle = e->n_sched_vehicles;
   const double elapsed0 = e->C.elapsed;
   if (nS > 0) {
-    HIPOK(hipMemcpyAsync(e->d_perm, e->hrank, (size_t)nS * 4, hipMemcpyHostToDevice, st));
+    if (e->sh_err) return fail(e, TS_E_DEVICE, "the shuffle thread could not send the permutation to the device");
+    HIPOK(hipStreamWaitEvent(st, e->perm_ev, 0));   // the permutation went up on its own stream while the decide phase ran
     hipLaunchKernelGGL(k_rank_invert, dim3(nblk(nS)), dim3(BLK), 0, st, e->d_perm, d.rank, nS);
     HIPOK(hipMemsetAsync(d.resolved, 0, (size_t)nS, st));
     HIPOK(hipMemsetAsync(&d.cnt->resolved, 0, sizeof(int) * 2, st));  // resolved, deaths
@@ -2320,6 +2372,9 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   ok = hipHostMalloc((void**)&e->h_words, MTPipe::TW_CAP * 4) == hipSuccess;
   ok &= dalloc(e, &d.words, (size_t)MTPipe::TW_CAP) == hipSuccess;
   ok &= hipStreamCreate(&e->copy_stream) == hipSuccess;
+  ok &= hipStreamCreateWithFlags(&e->perm_stream, hipStreamNonBlocking) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&e->perm_ev, hipEventDisableTiming) == hipSuccess;
+  e->device = g_device;
   ok &= hipEventCreateWithFlags(&e->words_ev, hipEventDisableTiming) == hipSuccess;
   if (!ok) return bail(TS_E_DEVICE);
   e->rng_global.use_storage(e->h_words);
@@ -2341,7 +2396,10 @@ int ts_destroy(ts_handle e) {
     { std::lock_guard<std::mutex> lk(e->sh_mu); e->sh_quit = true; }
     e->sh_cv.notify_all();
     e->sh_thread.join();
+    e->sh2_thread.join();
   }
+  if (e->perm_stream) { (void)hipStreamSynchronize(e->perm_stream); (void)hipStreamDestroy(e->perm_stream); }
+  if (e->perm_ev) (void)hipEventDestroy(e->perm_ev);
   for (void* p : e->allocs) (void)hipFree(p);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->hF) (void)hipHostFree(e->hF);
