@@ -159,7 +159,7 @@ __device__ int astar_dev(const Dev& d, const TsParams& P, AScratch& S, int start
     }
     S.expansions++;
     const int cx = cur % W, cy = cur / W;
-    const uint8_t bits = d.allowed[cur];
+    const uint8_t bits = (uint8_t)st_allowed(d.cell[cur].stat);
     for (int dd = 0; dd < 4; dd++) {
       const int nx = cx + (dd == 1) - (dd == 3), ny = cy + (dd == 0) - (dd == 2);
       if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
@@ -168,11 +168,12 @@ __device__ int astar_dev(const Dev& d, const TsParams& P, AScratch& S, int start
       const int nidx = ny * W + nx;
       double ng = g + 1;
       if (P.turn_penalty_enabled && prev_dir != -1 && dd != prev_dir) ng += P.turn_penalty;
+      const Cell nc = d.cell[nidx];   // one 32-byte load: occupancy, stop and the static byte of the neighbour
       if ((bits & (1 << dd)) == 0) {
-        if (ignore_flow && d.is_road[nidx] == 1) ng += P.contraflow_penalty;
+        if (ignore_flow && st_is_road(nc.stat) == 1) ng += P.contraflow_penalty;
         else continue;
       }
-      if (d.occ[nidx] == 1) {
+      if (nc.occ == 1) {
         if (soft && P.dynamic_penalties_enabled) {
           double p = P.obstacle_penalty_vehicle;
           double local_density = (double)d.density[nidx];
@@ -180,12 +181,12 @@ __device__ int astar_dev(const Dev& d, const TsParams& P, AScratch& S, int start
         } else if (soft) ng += P.obstacle_penalty_vehicle;
         else continue;
       }
-      if (d.stop[nidx] == 1) {
+      if (nc.stop == 1) {
         if (soft) ng += P.obstacle_penalty_stop;
         else continue;
       }
-      if (P.road_type_penalties_enabled && d.is_road[nidx] == 1) {
-        int rt = d.road_type[nidx];
+      if (P.road_type_penalties_enabled && st_is_road(nc.stat) == 1) {
+        int rt = st_road_type(nc.stat);
         if (rt == 1) ng += P.road_type_penalty_r1;
         else if (rt == 2) ng += P.road_type_penalty_r2;
         else if (rt == 3) ng += P.road_type_penalty_r3;
@@ -262,17 +263,55 @@ __device__ __forceinline__ int vw_path_cell(const Dev& d, const AScratch* S, con
   return walk;
 }
 
-// _scan_ahead_for_obstacles (vehicle_base.py:422-452)
+// _scan_ahead_for_obstacles (vehicle_base.py:422-452).  The cells are decoded first and their records loaded
+// together (independent loads, one memory round trip); the reference's early exit at index 0 only shortens the
+// evaluation.
+constexpr int SCAN_MAX = 16;
 __device__ void scan_ahead_dev(const Dev& d, const TsParams& P, const AScratch* S, const VW& v, int& idx_stop,
                                int& idx_veh, int& first_cell) {
   idx_stop = -1; idx_veh = -1; first_cell = -1;
-  int look = min(P.vehicle_awareness_range, v.plen);
+  const int look = min(P.vehicle_awareness_range, v.plen);
   int walk = v.pos;
+  if (look <= SCAN_MAX && !v.newpath) {
+    int cells[SCAN_MAX];
+    uint32_t dyn[SCAN_MAX];   // the dword holding occ / stop / stuck / stat
+    // the next 16 steps are at most 32 bits of the direction string: two pool words, decoded in registers
+    const uint32_t wi = (uint32_t)v.pcur >> 4, nwords = ((uint32_t)(v.pcur + v.plen) + 15u) >> 4;
+    uint64_t bits = d.pool[v.off + wi];
+    if (wi + 1 < nwords) bits |= (uint64_t)d.pool[v.off + wi + 1] << 32;
+    bits >>= (v.pcur & 15) * 2;
+    {
+      int c = v.pos;
+#pragma unroll
+      for (int k = 0; k < SCAN_MAX; k++) {
+        if (k < look) c = step_cell(c, (int)((bits >> (2 * k)) & 3), d.W);
+        cells[k] = c;
+      }
+    }
+    if (look > 0) first_cell = cells[0];
+    // an obstacle at index 0 ends the scan (the reference's break can only fire there) - and in dense traffic that
+    // is the common case, so the first record is fetched alone and the other nine only if it is clear
+    dyn[0] = look > 0 ? *reinterpret_cast<const uint32_t*>(&d.cell[cells[0]].occ) : 0u;
+    if (look > 0 && (int8_t)((dyn[0] >> 8) & 0xFF) == 1) idx_stop = 0;
+    if (look > 0 && (int8_t)(dyn[0] & 0xFF) == 1) idx_veh = 0;
+    if (idx_stop == 0 || idx_veh == 0) return;
+#pragma unroll
+    for (int k = 1; k < SCAN_MAX; k++) dyn[k] = k < look ? *reinterpret_cast<const uint32_t*>(&d.cell[cells[k]].occ) : 0u;
+#pragma unroll
+    for (int k = 1; k < SCAN_MAX; k++) {
+      const bool in = k < look;
+      const int occ = (int8_t)(dyn[k] & 0xFF), stop = (int8_t)((dyn[k] >> 8) & 0xFF);
+      if (in && idx_stop < 0 && stop == 1) idx_stop = k;
+      if (in && idx_veh < 0 && occ == 1) idx_veh = k;
+    }
+    return;
+  }
   for (int k = 0; k < look; k++) {
     int c = vw_path_cell(d, S, v, k, walk);
     if (k == 0) first_cell = c;
-    if (idx_stop < 0 && d.stop[c] == 1) idx_stop = k;
-    if (idx_veh < 0 && d.occ[c] == 1) idx_veh = k;
+    const Cell cc = d.cell[c];
+    if (idx_stop < 0 && cc.stop == 1) idx_stop = k;
+    if (idx_veh < 0 && cc.occ == 1) idx_veh = k;
     if (idx_stop == 0 || idx_veh == 0) break;
   }
 }
@@ -292,7 +331,7 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
     int merge_idx = -1, b = -1;
     for (int q = 0; q < v.ax_len[kp]; q++) {
       int c = r.next();
-      if (d.occ[c] == 0) { merge_idx = q; b = c; break; }
+      if (d.cell[c].occ == 0) { merge_idx = q; b = c; break; }
     }
     if (merge_idx < 0) continue;
     int bl = astar_dev(d, P, S, v.pos, b, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
@@ -332,15 +371,15 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
     int idx_stop = -1, idx_veh = -1;
     int look = min(P.vehicle_awareness_range, la);
     for (int q = 0; q < look; q++) {
-      if (idx_stop < 0 && d.stop[S.A[q]] == 1) idx_stop = q;
-      if (idx_veh < 0 && d.occ[S.A[q]] == 1) idx_veh = q;
+      if (idx_stop < 0 && d.cell[S.A[q]].stop == 1) idx_stop = q;
+      if (idx_veh < 0 && d.cell[S.A[q]].occ == 1) idx_veh = q;
       if (idx_stop >= 0 && idx_veh >= 0) break;
     }
     if (idx_veh == 0) {
-      int bk = d.cell_veh[S.A[0]];
+      int bk = d.cell[S.A[0]].veh;
       if (bk >= 0 && (seen_stranded(d, bk, v.i) || seen_parked(d, bk, v.i))) {
         int bt = -1, idx_bp = -1;
-        for (int q = 0; q < la; q++) if (d.occ[S.A[q]] == 0) { bt = S.A[q]; idx_bp = q; break; }
+        for (int q = 0; q < la; q++) if (d.cell[S.A[q]].occ == 0) { bt = S.A[q]; idx_bp = q; break; }
         if (bt >= 0) {
           int bl = astar_dev(d, P, S, v.pos, bt, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
           if (bl < 0) return false;
@@ -367,10 +406,10 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
   }
   // ---- phase 4: stuck detour (369-418) ----
   if (P.stuck_contraflow_enabled && la > 0) {
-    int threshold = d.inter[v.pos] == 1 ? P.stuck_contraflow_threshold_intersection : P.stuck_contraflow_threshold;
+    int threshold = st_inter(d.cell[v.pos].stat) == 1 ? P.stuck_contraflow_threshold_intersection : P.stuck_contraflow_threshold;
     if (v.stuck_ticks >= threshold) {
       int bt = -1, merge_idx = -1;
-      for (int q = 0; q < la; q++) if (d.occ[S.A[q]] == 0) { bt = S.A[q]; merge_idx = q; break; }
+      for (int q = 0; q < la; q++) if (d.cell[S.A[q]].occ == 0) { bt = S.A[q]; merge_idx = q; break; }
       if (bt >= 0) {
         int bl = astar_dev(d, P, S, v.pos, bt, true, true, P.max_contraflow_stuck_detour_steps, S.BYP, MAXB);
         if (bl < 0) return false;
@@ -469,7 +508,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
       dc_malf++;
       v.base = 0; v.cur = 0; early = true;
     }
-    if (!early && d.stop[v.pos] == 1) { v.base = 0; v.cur = 0; early = true; }
+    if (!early && d.cell[v.pos].stop == 1) { v.base = 0; v.cur = 0; early = true; }
   }
   int max_steps = d.max_steps[vid];
   bool path_changed = false, reached_body = false, arrived = false;
@@ -487,7 +526,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
     v.stuck_ticks = d.stuck_ticks[vid];
     for (int k = 0; k < 4; k++) { v.ax_staged[k] = false; v.ax_len[k] = d.ax_len[k][vid]; }
     // _recompute_path_on_stuck (506-517): self.path = self._compute_path(use_cache=False)
-    const int thresh = d.inter[v.pos] == 1 ? P.stuck_recompute_threshold_intersection : P.stuck_recompute_threshold;
+    const int thresh = st_inter(d.cell[v.pos].stat) == 1 ? P.stuck_recompute_threshold_intersection : P.stuck_recompute_threshold;
     if (v.stuck_ticks >= thresh) {
       if (!S) return DV_DEFER;
       v.cooldown = P.pathfinding_cooldown;
@@ -515,7 +554,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
     }
     if (!done_obst && v.cooldown > 0) {
       if (idx_veh == 0) {
-        int b = d.cell_veh[first_cell];
+        int b = d.cell[first_cell].veh;
         if (b >= 0 && (seen_stranded(d, b, i) || seen_parked(d, b, i))) {
           // immediate pathfinding
         } else { v.cooldown -= 1; done_obst = true; }
@@ -767,7 +806,7 @@ __global__ void k_reach_strict(Dev d, const int32_t* list, int n_list, uint32_t*
     const int idx = head + lane;
     const int c = idx < tail ? queue[idx] : -1;
     head = min(tail, head + 64);
-    const uint8_t bits = c >= 0 ? d.allowed[c] : 0;
+    const uint8_t bits = c >= 0 ? (uint8_t)st_allowed(d.cell[c].stat) : 0;
     const int cx = c >= 0 ? c % W : 0, cy = c >= 0 ? c / W : 0;
     for (int dd = 0; dd < 4; dd++) {
       int n = -1;
@@ -775,7 +814,8 @@ __global__ void k_reach_strict(Dev d, const int32_t* list, int n_list, uint32_t*
         const int nx = cx + (dd == 1) - (dd == 3), ny = cy + (dd == 0) - (dd == 2);
         if (nx >= 0 && nx < W && ny >= 0 && ny < H) {
           const int nidx = ny * W + nx;
-          if (d.occ[nidx] != 1 && d.stop[nidx] != 1) {
+          const Cell nc = d.cell[nidx];
+          if (nc.occ != 1 && nc.stop != 1) {
             const uint32_t bit = 1u << (nidx & 31);
             if (!(atomicOr(&visited[nidx >> 5], bit) & bit)) n = nidx;
           }

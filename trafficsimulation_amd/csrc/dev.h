@@ -45,12 +45,30 @@ struct DevCnt {
   int pad_;
 };
 
+// Everything the hot kernels read or write about one grid cell, in one 32-byte sector: the four move-phase claim
+// words (plane 0 = writers of occupancy, 1 = readers of occupancy, 2 = writers of stop, 3 = readers of stop), the head
+// of the cell's MultiGrid vehicle list, the dynamic bytes and the packed static byte.  Every field is written with
+// its own byte / dword store (agents that run in the same round touch different fields), never read-modify-write.
+struct __attribute__((aligned(32))) Cell {
+  uint32_t claim[4];
+  int32_t veh;                 // first vehicle in the cell's list, -1 = none
+  int8_t occ, stop, stuck;     // occupancy_map / stop_map / stuck_map
+  uint8_t stat;                // allowed_dirs (bits 0-3) | is_road << 4 | intersection << 5 | road_type << 6
+  uint32_t pad_[2];
+};
+__host__ __device__ __forceinline__ int st_allowed(uint8_t s) { return s & 15; }
+__host__ __device__ __forceinline__ int st_is_road(uint8_t s) { return (s >> 4) & 1; }
+__host__ __device__ __forceinline__ int st_inter(uint8_t s) { return (s >> 5) & 1; }
+__host__ __device__ __forceinline__ int st_road_type(uint8_t s) { return (s >> 6) & 3; }
+
 struct Dev {
   int W, H, N;
   double elapsed;   // DynamicTrafficAgent.elapsed as the decide phase sees it (before the clock agent steps)
-  int8_t *occ, *stop, *stuck, *rain;
-  uint8_t* allowed;
-  int8_t *is_road, *road_type, *inter;
+  Cell* cell;
+  // dense byte planes kept next to the records: occ and stop are written through (light groups sum lanes of
+  // occupancy, the density map and the host read whole planes), rain is only ever read at a vehicle's own cell
+  int8_t *occ, *stop, *rain;
+  int8_t* is_road;  // static plane for the density map
   // vehicles (indexed by vehicle id = spawn index)
   int32_t *pos, *target, *path_len, *path_cur, *stuck_ticks, *cooldown, *stranded_left, *steps, *over_dur, *det_dur,
       *next_in_cell, *active_idx, *sched_slot;
@@ -70,7 +88,6 @@ struct Dev {
   uint8_t* reach;    // per vehicle, this tick: 0 = unknown, 1 = target reachable under strict rules, 2 = not
   float* density;    // _update_density_map (city_model.py:1764-1778), materialised on demand
   int8_t* occ_snap;  // occupancy at the last tick start (what density_map is a function of)
-  int32_t* cell_veh;  // first vehicle in the cell's MultiGrid list, -1 = none
   // ordered lists
   int32_t* active;    // active_vehicle_agents (vehicle ids, -1 = removed this tick)
   int8_t* sched_kind;
@@ -88,10 +105,8 @@ struct Dev {
       *g_nb_ctor, *g_slot;
   int32_t *gs_cur, *gs_pend, *gs_trans, *gs_clear, *gs_ftphase, *gs_fttimer, *gs_qtimer, *gs_gap, *gs_last, *gs_nsp,
       *gs_ewp, *gs_repop;
-  // per-cell min-rank claims for the move phase (epoch-tagged so they never need clearing)
-  // the four claim words of a cell are adjacent (one 16-byte record per cell): plane 0 = writers of occupancy,
-  // 1 = readers of occupancy, 2 = writers of stop, 3 = readers of stop
-  uint32_t *claims, *gclaim_r;
+  // per-cell min-rank claims for the move phase live in Cell::claim (epoch-tagged so they never need clearing)
+  uint32_t* gclaim_r;
   // decide-phase exchange buffers
   uint8_t *F, *R;
   int32_t* cand;
@@ -107,6 +122,8 @@ __device__ __forceinline__ int path_dir(const uint32_t* pool, uint32_t off, int 
 __device__ __forceinline__ int step_cell(int cell, int dir, int W) {
   return dir == 0 ? cell + W : dir == 1 ? cell + 1 : dir == 2 ? cell - W : cell - 1;
 }
+__device__ __forceinline__ void set_occ(const Dev& d, int c, int8_t v) { d.cell[c].occ = v; d.occ[c] = v; }
+__device__ __forceinline__ void set_stop(const Dev& d, int c, int8_t v) { d.cell[c].stop = v; d.stop[c] = v; }
 __device__ __forceinline__ uint32_t claim_rank(uint32_t v, uint32_t prefix) {
   return (v >> RANK_BITS) == prefix ? (v & RANK_MASK) : NO_RANK;
 }

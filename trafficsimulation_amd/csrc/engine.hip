@@ -64,12 +64,12 @@ __global__ void k_decide_pre(Dev d, TsParams P, int start, int n_active) {
           int ld = k == 0 ? ((dir + 3) & 3) : ((dir + 1) & 3);  // left, then right
           int nx = x + (ld == 1) - (ld == 3), ny = y + (ld == 0) - (ld == 2);
           if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
-          for (int ag = d.cell_veh[ny * W + nx]; ag >= 0; ag = d.next_in_cell[ag]) {
+          for (int ag = d.cell[ny * W + nx].veh; ag >= 0; ag = d.next_in_cell[ag]) {
             uint16_t af = d.flags[ag];
             bool earlier = d.active_idx[ag] < i;
             bool ag_sb = (af & (VF_COLL | VF_MALF)) != 0;
             bool ag_str = earlier ? (d.ev[ag] ? true : ((ag_sb && d.stranded_left[ag] - 1 > 0) || !P.malfunction_active)) : ag_sb;
-            bool cs_pos = earlier ? (!ag_str && d.stop[d.pos[ag]] != 1) : (d.cur_speed[ag] > 0);
+            bool cs_pos = earlier ? (!ag_str && d.cell[d.pos[ag]].stop != 1) : (d.cur_speed[ag] > 0);
             if (!cs_pos || (af & (VF_STUCK | VF_PARKED)) || ag_str) continue;
             if (earlier && (af & VF_KEEP) && d.pos[ag] == d.target[ag]) continue;   // it parked inside its own step_decide
             if (d.dir[ag] != opposite) continue;
@@ -79,7 +79,7 @@ __global__ void k_decide_pre(Dev d, TsParams P, int start, int n_active) {
         }
         if (cand >= 0) F |= F_DRAW_SWIPE;
       }
-      if (d.stop[pos] != 1 && d.base_speed[vid] == 0) F |= F_DRAW_SPEED;
+      if (d.cell[pos].stop != 1 && d.base_speed[vid] == 0) F |= F_DRAW_SPEED;
     }
   }
   d.F[i] = F;
@@ -135,7 +135,7 @@ __global__ void k_apply_event(Dev d, TsParams P, int vid, int is_collision, int 
 // ---------------------------------------------------------------------------------------------
 // move phase
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void claim(uint32_t* arr, int cell, uint32_t key) { atomicMin(&arr[cell], key); }
+__device__ __forceinline__ void claim(const Dev& d, int cell, int plane, uint32_t key) { atomicMin(&d.cell[cell].claim[plane], key); }
 
 __device__ __forceinline__ bool group_reads_out(const TsParams& P) {
   return P.light_algorithm == TS_LIGHTS_PRESSURE_CONTROL || P.light_algorithm == TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL;
@@ -162,32 +162,32 @@ __global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix, co
     const int pos = d.pos[vid];
     if (f & VF_SERVICING) return;   // ServiceVehicleAgent.step only counts down (vehicle_service.py:43-49)
     if (f & VF_EARLY) {
-      if (d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED) claim(d.claims, (pos) * 4 + 3, key);  // tick_stuck reads stop[pos]
-      if (pos == d.target[vid]) claim(d.claims, (pos) * 4 + 0, key);
+      if (d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED) claim(d, pos, 3, key);  // tick_stuck reads stop[pos]
+      if (pos == d.target[vid]) claim(d, pos, 0, key);
     } else {
       const int m = d.max_steps[vid];
-      claim(d.claims, (pos) * 4 + 0, key);
+      claim(d, pos, 0, key);
       const uint32_t off = d.path_off[vid];
       const int pcur = d.path_cur[vid];
       int c = pos;
       for (int k = 0; k < m; k++) {
         c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
-        claim(d.claims, (c) * 4 + 0, key);
-        if (d.G > 0) claim(d.claims, (c) * 4 + 3, key);
+        claim(d, c, 0, key);
+        if (d.G > 0) claim(d, c, 3, key);
       }
     }
   } else if (kind == TS_AGENT_LIGHT_GROUP && P.light_algorithm != TS_LIGHTS_DISABLED) {
     const int g = d.sched_ref[s];
-    for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1]; k++) claim(d.claims, (d.g_icell[k]) * 4 + 1, key);
-    for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1]; k++) claim(d.claims, (d.g_nsin[k]) * 4 + 1, key);
-    for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1]; k++) claim(d.claims, (d.g_ewin[k]) * 4 + 1, key);
+    for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1]; k++) claim(d, d.g_icell[k], 1, key);
+    for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1]; k++) claim(d, d.g_nsin[k], 1, key);
+    for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1]; k++) claim(d, d.g_ewin[k], 1, key);
     if (group_reads_out(P)) {
-      for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1]; k++) claim(d.claims, (d.g_nsout[k]) * 4 + 1, key);
-      for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1]; k++) claim(d.claims, (d.g_ewout[k]) * 4 + 1, key);
+      for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1]; k++) claim(d, d.g_nsout[k], 1, key);
+      for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1]; k++) claim(d, d.g_ewout[k], 1, key);
     }
     for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1]; l++) {
-      claim(d.claims, (d.light_cell[l]) * 4 + 2, key);
-      for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) claim(d.claims, (d.light_ctrl[k]) * 4 + 2, key);
+      claim(d, d.light_cell[l], 2, key);
+      for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) claim(d, d.light_ctrl[k], 2, key);
     }
     if (group_reads_neighbors(P)) {
       for (int k = 0; k < 4; k++) {
@@ -200,15 +200,15 @@ __global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix, co
 }
 
 __device__ __forceinline__ void cell_unlink(const Dev& d, int cell, int vid) {
-  int h = d.cell_veh[cell];
-  if (h == vid) { d.cell_veh[cell] = d.next_in_cell[vid]; return; }
+  int h = d.cell[cell].veh;
+  if (h == vid) { d.cell[cell].veh = d.next_in_cell[vid]; return; }
   while (h >= 0 && d.next_in_cell[h] != vid) h = d.next_in_cell[h];
   if (h >= 0) d.next_in_cell[h] = d.next_in_cell[vid];
 }
 __device__ __forceinline__ void cell_append(const Dev& d, int cell, int vid) {
   d.next_in_cell[vid] = -1;
-  int h = d.cell_veh[cell];
-  if (h < 0) { d.cell_veh[cell] = vid; return; }
+  int h = d.cell[cell].veh;
+  if (h < 0) { d.cell[cell].veh = vid; return; }
   while (d.next_in_cell[h] >= 0) h = d.next_in_cell[h];
   d.next_in_cell[h] = vid;
 }
@@ -237,7 +237,7 @@ __device__ void on_target_reached_dev(const Dev& d, const TsParams& P, int vid, 
     }
   }
   if (!(f & VF_KEEP)) {
-    d.occ[pos] = 0; d.stuck[pos] = 0;
+    set_occ(d, pos, 0); d.cell[pos].stuck = 0;
     cell_unlink(d, pos, vid);
     f &= ~VF_ALIVE;
     d.sched_kind[s] = K_DEAD;
@@ -256,7 +256,12 @@ __device__ void on_target_reached_dev(const Dev& d, const TsParams& P, int vid, 
 
 // VehicleAgent.step with PATHFINDING_BATCHING (vehicle_base.py:666-685): _execute_movement 733-753,
 // _move_to 521-532 + CityModel.move_vehicle (city_model.py:1945-1963), tick_stuck 687-693.
-__device__ void vehicle_step_dev(const Dev& d, const TsParams& P, int vid, int s, double elapsed_now, int key) {
+// `cells` / `recs`: the vehicle's cell and the next max_steps path cells with their records as k_move_resolve
+// loaded them for the claim test (nothing can have changed them since: that is what "safe" means); pass nullptr
+// to read them here.
+constexpr int MOVE_MAX = 8;
+__device__ __forceinline__ void vehicle_step_dev(const Dev& d, const TsParams& P, int vid, int s, double elapsed_now, int key,
+                                                 const bool pre, const int (&cells)[MOVE_MAX + 1], const uint4 (&dyn)[MOVE_MAX + 1]) {
   uint16_t f = d.flags[vid];
   if (f & VF_SERVICING) return;   // the countdown and _finish_service are host state
   int pos = d.pos[vid];
@@ -267,15 +272,35 @@ __device__ void vehicle_step_dev(const Dev& d, const TsParams& P, int vid, int s
     const int plen = d.path_len[vid] - pcur;
     const bool was_stuck = (f & VF_STUCK) != 0;
     int c = pos, moved = 0, lastdir = -1;
-    for (int k = 0; k < m; k++) {
-      if (k >= plen) break;
-      int nd = path_dir(d.pool, off, pcur + k);
-      int nc = step_cell(c, nd, d.W);
-      if (d.occ[nc] == 1) break;
-      if (d.stop[nc] == 1 && k != m - 1) break;
-      d.occ[c] = 0; d.occ[nc] = 1;
-      d.stuck[c] = 0; d.stuck[nc] = (k == 0 && was_stuck) ? 1 : 0;
-      c = nc; moved++; lastdir = nd;
+    if (pre) {
+      bool go = true;
+#pragma unroll
+      for (int k = 0; k < MOVE_MAX; k++) {
+        if (go && k < m && k < plen) {
+          const int nc = cells[k + 1];
+          const uint32_t dw = dyn[k + 1].y;   // occ | stop << 8 | stuck << 16 | stat << 24
+          const int occ = (int8_t)(dw & 0xFF), stop = (int8_t)((dw >> 8) & 0xFF);
+          if (occ == 1 || (stop == 1 && k != m - 1)) go = false;
+          else {
+            set_occ(d, c, 0); set_occ(d, nc, 1);
+            d.cell[c].stuck = 0; d.cell[nc].stuck = (k == 0 && was_stuck) ? 1 : 0;
+            lastdir = nc == c + d.W ? 0 : nc == c + 1 ? 1 : nc == c - d.W ? 2 : 3;
+            c = nc; moved++;
+          }
+        }
+      }
+    } else {
+      for (int k = 0; k < m; k++) {
+        if (k >= plen) break;
+        const int nd = path_dir(d.pool, off, pcur + k);
+        const int nc = step_cell(c, nd, d.W);
+        const Cell ncell = d.cell[nc];
+        if (ncell.occ == 1) break;
+        if (ncell.stop == 1 && k != m - 1) break;
+        set_occ(d, c, 0); set_occ(d, nc, 1);
+        d.cell[c].stuck = 0; d.cell[nc].stuck = (k == 0 && was_stuck) ? 1 : 0;
+        c = nc; moved++; lastdir = nd;
+      }
     }
     if (moved) {
       cell_unlink(d, pos, vid);
@@ -293,7 +318,8 @@ __device__ void vehicle_step_dev(const Dev& d, const TsParams& P, int vid, int s
     f |= VF_HASPREV;
   } else {
     f &= ~VF_EARLY;
-    if ((f & VF_HASPREV) && d.stop[pos] != 1) {
+    const int stop_here = pre ? (int)(int8_t)((dyn[0].y >> 8) & 0xFF) : (int)d.cell[pos].stop;
+    if ((f & VF_HASPREV) && stop_here != 1) {
       int st = d.stuck_ticks[vid] + 1;
       d.stuck_ticks[vid] = st;
       if (st > P.stuck_recompute_threshold && !(f & VF_STUCK)) {
@@ -307,8 +333,8 @@ __device__ void vehicle_step_dev(const Dev& d, const TsParams& P, int vid, int s
 }
 
 __device__ __forceinline__ void light_set(const Dev& d, int l, int8_t v) {  // cell.py:241-251
-  d.stop[d.light_cell[l]] = v;
-  for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) d.stop[d.light_ctrl[k]] = v;
+  set_stop(d, d.light_cell[l], v);
+  for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) set_stop(d, d.light_ctrl[k], v);
 }
 __device__ __forceinline__ int queue_sum(const Dev& d, const int32_t* off, const int32_t* cells, int g) {
   int q = 0;  // compute_approach_queue (numba_utilities.py:65-72)
@@ -422,46 +448,86 @@ __global__ void k_move_resolve(Dev d, TsParams P, int n_sched, uint32_t prefix, 
     const uint16_t f = d.flags[vid];
     const int pos = d.pos[vid];
     const bool lights = d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED;
+    // The vehicle's own cell and the cells it may enter: decode them, then load their records together (the
+    // claim words in .x-.w of the first 16 bytes, the dynamic dword right behind) - one memory round trip for
+    // both the claim test and the movement.
+    int cells[MOVE_MAX + 1];
+    uint4 claims[MOVE_MAX + 1], dyn[MOVE_MAX + 1];
+    const int m = (f & (VF_EARLY | VF_SERVICING)) ? 0 : (int)d.max_steps[vid];
+    const bool fast = m <= MOVE_MAX;
+    if (fast) {
+      const uint32_t off = d.path_off[vid];
+      const int pcur = d.path_cur[vid];
+      // the next 8 steps are at most 16 bits of the direction string: two pool words, decoded in registers
+      uint64_t bits = 0;
+      if (m > 0) {
+        const uint32_t wi = (uint32_t)pcur >> 4, nwords = ((uint32_t)d.path_len[vid] + 15u) >> 4;
+        bits = d.pool[off + wi];
+        if (wi + 1 < nwords) bits |= (uint64_t)d.pool[off + wi + 1] << 32;
+        bits >>= (pcur & 15) * 2;
+      }
+      int c = pos;
+      cells[0] = pos;
+#pragma unroll
+      for (int k = 0; k < MOVE_MAX; k++) {
+        if (k < m) c = step_cell(c, (int)((bits >> (2 * k)) & 3), d.W);
+        cells[k + 1] = c;
+      }
+#pragma unroll
+      for (int k = 0; k <= MOVE_MAX; k++) {
+        if (k <= m) {
+          const uint4* rp = reinterpret_cast<const uint4*>(&d.cell[cells[k]]);
+          claims[k] = rp[0];
+          dyn[k] = rp[1];   // .x = veh, .y = occ | stop << 8 | stuck << 16 | stat << 24
+        }
+      }
+    }
     if (f & VF_SERVICING) {
       // nothing on the maps is read or written
     } else if (f & VF_EARLY) {
-      if (lights && claim_rank(d.claims[(pos) * 4 + 2], prefix) < r) safe = false;
-      if (pos == d.target[vid] && (claim_rank(d.claims[(pos) * 4 + 0], prefix) < r || claim_rank(d.claims[(pos) * 4 + 1], prefix) < r))
-        safe = false;
+      const uint4 cl = fast ? claims[0] : *reinterpret_cast<const uint4*>(&d.cell[pos]);
+      if (lights && claim_rank(cl.z, prefix) < r) safe = false;
+      if (pos == d.target[vid] && (claim_rank(cl.x, prefix) < r || claim_rank(cl.y, prefix) < r)) safe = false;
+    } else if (fast) {
+#pragma unroll
+      for (int k = 0; k <= MOVE_MAX; k++) {
+        if (k <= m && (claim_rank(claims[k].x, prefix) < r || claim_rank(claims[k].y, prefix) < r)) safe = false;
+        if (k > 0 && k <= m && lights && claim_rank(claims[k].z, prefix) < r) safe = false;
+      }
     } else {
-      const int m = d.max_steps[vid];
-      if (claim_rank(d.claims[(pos) * 4 + 0], prefix) < r || claim_rank(d.claims[(pos) * 4 + 1], prefix) < r) safe = false;
+      const int mm = d.max_steps[vid];
+      if (claim_rank(d.cell[pos].claim[0], prefix) < r || claim_rank(d.cell[pos].claim[1], prefix) < r) safe = false;
       const uint32_t off = d.path_off[vid];
       const int pcur = d.path_cur[vid];
       int c = pos;
-      for (int k = 0; k < m && safe; k++) {
+      for (int k = 0; k < mm && safe; k++) {
         c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
-        if (claim_rank(d.claims[(c) * 4 + 0], prefix) < r || claim_rank(d.claims[(c) * 4 + 1], prefix) < r) safe = false;
-        if (lights && claim_rank(d.claims[(c) * 4 + 2], prefix) < r) safe = false;
+        if (claim_rank(d.cell[c].claim[0], prefix) < r || claim_rank(d.cell[c].claim[1], prefix) < r) safe = false;
+        if (lights && claim_rank(d.cell[c].claim[2], prefix) < r) safe = false;
       }
     }
     if (!safe) { out_list[atomicAdd(out_n, 1)] = s; return; }
-    vehicle_step_dev(d, P, vid, s, elapsed0 + (r > rank_clock ? (double)P.time_per_step_seconds : 0.0), (int)r);
+    vehicle_step_dev(d, P, vid, s, elapsed0 + (r > rank_clock ? (double)P.time_per_step_seconds : 0.0), (int)r, fast, cells, dyn);
   } else if (kind == TS_AGENT_LIGHT_GROUP && P.light_algorithm != TS_LIGHTS_DISABLED) {
     const int g = d.sched_ref[s];
     for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1] && safe; k++)
-      if (claim_rank(d.claims[(d.g_icell[k]) * 4 + 0], prefix) < r) safe = false;
+      if (claim_rank(d.cell[d.g_icell[k]].claim[0], prefix) < r) safe = false;
     for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1] && safe; k++)
-      if (claim_rank(d.claims[(d.g_nsin[k]) * 4 + 0], prefix) < r) safe = false;
+      if (claim_rank(d.cell[d.g_nsin[k]].claim[0], prefix) < r) safe = false;
     for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1] && safe; k++)
-      if (claim_rank(d.claims[(d.g_ewin[k]) * 4 + 0], prefix) < r) safe = false;
+      if (claim_rank(d.cell[d.g_ewin[k]].claim[0], prefix) < r) safe = false;
     if (group_reads_out(P)) {
       for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1] && safe; k++)
-        if (claim_rank(d.claims[(d.g_nsout[k]) * 4 + 0], prefix) < r) safe = false;
+        if (claim_rank(d.cell[d.g_nsout[k]].claim[0], prefix) < r) safe = false;
       for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1] && safe; k++)
-        if (claim_rank(d.claims[(d.g_ewout[k]) * 4 + 0], prefix) < r) safe = false;
+        if (claim_rank(d.cell[d.g_ewout[k]].claim[0], prefix) < r) safe = false;
     }
     for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1] && safe; l++) {
       int lc = d.light_cell[l];
-      if (claim_rank(d.claims[(lc) * 4 + 2], prefix) < r || claim_rank(d.claims[(lc) * 4 + 3], prefix) < r) safe = false;
+      if (claim_rank(d.cell[lc].claim[2], prefix) < r || claim_rank(d.cell[lc].claim[3], prefix) < r) safe = false;
       for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1] && safe; k++) {
         int cc = d.light_ctrl[k];
-        if (claim_rank(d.claims[(cc) * 4 + 2], prefix) < r || claim_rank(d.claims[(cc) * 4 + 3], prefix) < r) safe = false;
+        if (claim_rank(d.cell[cc].claim[2], prefix) < r || claim_rank(d.cell[cc].claim[3], prefix) < r) safe = false;
       }
     }
     if (safe && group_reads_neighbors(P)) {
@@ -596,8 +662,8 @@ __global__ void k_spawn(Dev d, TsParams P, SpawnArgs a, int n, int vid0, int act
   for (int k = 0; k < 4; k++) { d.ax_len[k][vid] = 0; d.ax_off[k][vid] = 0; d.ax_start[k][vid] = pos; }
   d.active[active0 + i] = vid; d.active_idx[vid] = active0 + i;
   d.sched_kind[sched0 + i] = K_VEHICLE; d.sched_ref[sched0 + i] = vid; d.sched_slot[vid] = sched0 + i;
-  d.occ[pos] = 1; d.stuck[pos] = 0;  // place_vehicle (city_model.py:1897-1918)
-  if (a.serial[i] || atomicCAS(&d.cell_veh[pos], -1, vid) != -1) overflow[atomicAdd(n_overflow, 1)] = vid;
+  set_occ(d, pos, 1); d.cell[pos].stuck = 0;  // place_vehicle (city_model.py:1897-1918)
+  if (a.serial[i] || atomicCAS(&d.cell[pos].veh, -1, vid) != -1) overflow[atomicAdd(n_overflow, 1)] = vid;
 }
 __global__ void k_spawn_serial(Dev d, int* overflow, int n_overflow) {  // cells holding several vehicles: list order = spawn order
   if (threadIdx.x || blockIdx.x) return;
@@ -710,6 +776,34 @@ __global__ void k_rain_map(int8_t* rain, int W, int H, RainDiscs D) {
 }
 
 // rank[slot] = position of the slot in the shuffled key order
+// cell records <-> byte planes
+__global__ void k_cells_init(Cell* cell, int n, const uint8_t* allowed, const int8_t* is_road, const int8_t* road_type,
+                             const int8_t* inter) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  Cell x;
+  x.claim[0] = x.claim[1] = x.claim[2] = x.claim[3] = 0xFFFFFFFFu;
+  x.veh = -1; x.occ = 0; x.stop = 0; x.stuck = 0;
+  x.stat = (uint8_t)((allowed[c] & 15) | ((is_road[c] == 1) << 4) | ((inter[c] == 1) << 5) | ((road_type[c] & 3) << 6));
+  x.pad_[0] = x.pad_[1] = 0;
+  cell[c] = x;
+}
+__global__ void k_claims_reset(Cell* cell, int n) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  cell[c].claim[0] = cell[c].claim[1] = cell[c].claim[2] = cell[c].claim[3] = 0xFFFFFFFFu;
+}
+__global__ void k_plane_to_cells(Cell* cell, int n, const int8_t* plane, int which) {   // which: 0 occ, 1 stop
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  if (which == 0) cell[c].occ = plane[c]; else cell[c].stop = plane[c];
+}
+__global__ void k_cells_to_plane(const Cell* cell, int n, int8_t* plane) {   // stuck_map
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  plane[c] = cell[c].stuck;
+}
+
 // on_target_reached inside step_decide for the vehicles that stay (AR_DECIDE records): the flag changes other
 // deciders must not see half-way are applied once the decide kernels are done
 __global__ void k_decide_arrive(Dev d, int n_rec) {
@@ -2224,7 +2318,7 @@ int tick(E* e) {
         for (int rr = 0; rr < chunk; rr++, round_no++) {
           if ((e->epoch % EPOCHS) == 0) {  // epoch prefix wrapped: stale keys would win again -> clear once
             size_t n = (size_t)e->N;
-            HIPOK(hipMemsetAsync(d.claims, 0xFF, n * 16, st));
+            hipLaunchKernelGGL(k_claims_reset, dim3(nblk((long long)n)), dim3(BLK), 0, st, d.cell, (int)n);
             HIPOK(hipMemsetAsync(d.gclaim_r, 0xFF, (size_t)std::max(d.G, 1) * 4, st));
           }
           const uint32_t prefix = (EPOCHS - 1) - (e->epoch % EPOCHS);
@@ -2341,23 +2435,28 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   auto bail = [&](int code) { ts_destroy(e); return code; };
   if (hipStreamCreate(&e->stream) != hipSuccess) return bail(TS_E_DEVICE);
 #define A(ptr, n) if (dalloc(e, &ptr, (size_t)(n)) != hipSuccess) return bail(TS_E_DEVICE);
-  A(d.occ, N) A(d.stop, N) A(d.stuck, N) A(d.rain, N) A(d.allowed, N) A(d.is_road, N) A(d.road_type, N) A(d.inter, N)
-  A(d.cell_veh, N) A(d.claims, N * 4) A(d.gclaim_r, 1)
+  A(d.occ, N) A(d.stop, N) A(d.rain, N) A(d.is_road, N) A(d.cell, N) A(d.gclaim_r, 1)
+  uint8_t* t_allowed = nullptr;   // static planes only needed to build the cell records
+  int8_t *t_road_type = nullptr, *t_inter = nullptr;
+  if (hipMalloc((void**)&t_allowed, N) != hipSuccess || hipMalloc((void**)&t_road_type, N) != hipSuccess ||
+      hipMalloc((void**)&t_inter, N) != hipSuccess) {
+    (void)hipFree(t_allowed); (void)hipFree(t_road_type); (void)hipFree(t_inter);
+    return bail(TS_E_DEVICE);
+  }
   A(d.cnt, 1) A(e->d_total, 1) A(e->d_crc, 256) A(d.occ_snap, N) A(e->d_status, 4)
 #undef A
   hipStream_t st = e->stream;
   bool ok = true;
   ok &= hipMemsetAsync(d.occ, 0, N, st) == hipSuccess;
   ok &= hipMemsetAsync(d.stop, 0, N, st) == hipSuccess;
-  ok &= hipMemsetAsync(d.stuck, 0, N, st) == hipSuccess;
   ok &= hipMemsetAsync(d.rain, 0, N, st) == hipSuccess;
   ok &= hipMemsetAsync(d.occ_snap, 0, N, st) == hipSuccess;  // _update_density_map() on the fresh, empty model
-  ok &= hipMemsetAsync(d.cell_veh, 0xFF, N * 4, st) == hipSuccess;
   ok &= hipMemsetAsync(d.cnt, 0, sizeof(DevCnt), st) == hipSuccess;
-  ok &= hipMemcpyAsync(d.allowed, w->allowed_dirs_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(t_allowed, w->allowed_dirs_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
   ok &= hipMemcpyAsync(d.is_road, w->is_road_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
-  ok &= hipMemcpyAsync(d.road_type, w->road_type_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
-  ok &= hipMemcpyAsync(d.inter, w->intersection_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(t_road_type, w->road_type_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(t_inter, w->intersection_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
+  hipLaunchKernelGGL(k_cells_init, dim3(nblk((long long)N)), dim3(BLK), 0, st, d.cell, (int)N, t_allowed, d.is_road, t_road_type, t_inter);
   uint32_t table[256];
   for (uint32_t i = 0; i < 256; i++) {
     uint32_t c = i;
@@ -2368,6 +2467,7 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   ok &= hipHostMalloc((void**)&e->hcnt, sizeof(DevCnt)) == hipSuccess;
   ok &= hipHostMalloc((void**)&e->hint, sizeof(int) * 16) == hipSuccess;
   ok &= hipStreamSynchronize(st) == hipSuccess;
+  (void)hipFree(t_allowed); (void)hipFree(t_road_type); (void)hipFree(t_inter);
   if (!ok) return bail(TS_E_DEVICE);
   ok = hipHostMalloc((void**)&e->h_words, MTPipe::TW_CAP * 4) == hipSuccess;
   ok &= dalloc(e, &d.words, (size_t)MTPipe::TW_CAP) == hipSuccess;
@@ -2841,11 +2941,17 @@ int ts_upload_map(ts_handle e, int32_t which, const int8_t* src) {
   int8_t* m = which == TS_MAP_STOP ? e->d.stop : which == TS_MAP_RAIN ? e->d.rain : nullptr;
   if (!m) return fail(e, TS_E_INVALID, "only stop_map and rain_map are host-writable");
   HIPOK(hipMemcpy(m, src, e->N, hipMemcpyHostToDevice));
+  if (which == TS_MAP_STOP) {
+    hipLaunchKernelGGL(k_plane_to_cells, dim3(nblk((long long)e->N)), dim3(BLK), 0, e->stream, e->d.cell, e->N, e->d.stop, 1);
+    HIPOK(hipStreamSynchronize(e->stream));
+  }
   return TS_OK;
 }
 int ts_debug_set_occupancy(ts_handle e, const int8_t* src) {
   if (!e || !src) return TS_E_INVALID;
   HIPOK(hipMemcpy(e->d.occ, src, e->N, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_plane_to_cells, dim3(nblk((long long)e->N)), dim3(BLK), 0, e->stream, e->d.cell, e->N, e->d.occ, 0);
+  HIPOK(hipStreamSynchronize(e->stream));
   return TS_OK;
 }
 
@@ -2868,8 +2974,19 @@ int ts_num_scheduled(ts_handle e) { return e ? e->n_sched : TS_E_INVALID; }
 
 int ts_download_map(ts_handle e, int32_t which, int8_t* dst) {
   if (!e || !dst) return TS_E_INVALID;
+  HIPOK(hipStreamSynchronize(e->stream));
+  if (which == TS_MAP_STUCK) {   // lives only in the cell records
+    int8_t* tmp = nullptr;
+    HIPOK(hipMalloc((void**)&tmp, (size_t)e->N));
+    hipLaunchKernelGGL(k_cells_to_plane, dim3(nblk((long long)e->N)), dim3(BLK), 0, e->stream, e->d.cell, e->N, tmp);
+    hipError_t r = hipMemcpyAsync(dst, tmp, e->N, hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    (void)hipFree(tmp);
+    HIPOK(r);
+    return TS_OK;
+  }
   const int8_t* m = which == TS_MAP_OCCUPANCY ? e->d.occ : which == TS_MAP_STOP ? e->d.stop
-                   : which == TS_MAP_STUCK ? e->d.stuck : which == TS_MAP_RAIN ? e->d.rain : nullptr;
+                   : which == TS_MAP_RAIN ? e->d.rain : nullptr;
   if (!m) return TS_E_INVALID;
   HIPOK(hipMemcpy(dst, m, e->N, hipMemcpyDeviceToHost));
   return TS_OK;
