@@ -158,3 +158,61 @@ def test_facade_with_generator_on_hip(hip):
     CityBlock views read from the HIP engine."""
     from tests.test_mesa_facade import run_facade_with_generator
     run_facade_with_generator(hip)
+
+
+def test_hip_vs_oracle_service_stress():
+    """Service vehicles under stress on a reference-generated world whose block types are overridden so that a single
+    block needs food: a vehicle that still carries load is sent back to the cell it stands on (start == goal, empty
+    path) and runs on_target_reached -> _start_service inside step_decide (k_decide_arrive / seen_parked); a huge
+    fleet with tiny loads keeps several vehicles parked at once and contests the ranked service cells.  HIP engine
+    against the CPU oracle, state for state, up to and including the duplicate-id error both must report."""
+    from oracle import pyoracle
+    from trafficsimulation_amd._lib import new_engine
+    from trafficsimulation_amd.world import build_engine
+    tr = load_trace(trace_path("service_64_s15"))
+    tables = dict(tr)
+    tables["blk_type"] = np.asarray([0, 2, 0, 0], dtype=np.int32)
+    svc = dict(service_food=4000, service_waste=4000, load_time=3, max_load_food=5000.0, max_load_waste=3.0,
+               food_consumption_ticks=2, waste_production_ticks=3)
+    apis = []
+    for api in (new_engine(), pyoracle.load()):
+        build_engine(api, tables, defaults={"RAIN_ENABLED": False, "VEHICLE_MALFUNCTION_CHANCE": 0.002,
+                                            "VEHICLE_MALFUNCTION_DURATION": 15}, global_seed=77, sched_seed=78)
+        api.set_traffic_generator(tables, internal_per_day=2000, passing_per_day=3000, start_offset_seconds=6 * 3600, service=svc)
+        apis.append(api)
+    h, c = apis
+    own_cell_retargets, raised = 0, None
+    for t in range(400):
+        errs = []
+        for api in (h, c):
+            try:
+                api.step(1)
+                errs.append(None)
+            except capi.EngineError as ex:
+                errs.append(ex.code)
+        assert errs[0] == errs[1], f"tick {t}: hip {errs[0]} vs oracle {errs[1]}"
+        if errs[0] is not None:
+            raised = (t, errs[0])
+            break
+        a, b = h.vehicles(), c.vehicles()
+        assert a.shape == b.shape, f"tick {t}: live vehicles"
+        if not np.array_equal(a, b):
+            r, col = np.argwhere(a != b)[0]
+            raise AssertionError(f"tick {t}: vehicle row {r} field {capi.V_FIELDS[col]}: hip {a[r, col]} cpu {b[r, col]}")
+        ma, mb = h.vehicle_meta(), c.vehicle_meta()
+        assert np.array_equal(ma, mb), f"tick {t}: vehicle meta"
+        own_cell_retargets += int(np.sum((ma[:, 5] == 0) & (ma[:, 2] == a[:, 1]) & (ma[:, 3] == a[:, 2])))
+        for x, y in zip(h.service_vehicles(), c.service_vehicles()):
+            assert np.array_equal(x, y), f"tick {t}: service vehicle loads / blocks"
+        assert np.array_equal(h.blocks(), c.blocks()), f"tick {t}: block stock"
+        for which in (capi.MAP_OCCUPANCY, capi.MAP_STOP, capi.MAP_STUCK):
+            assert np.array_equal(h.map(which), c.map(which)), f"tick {t}: map {which}"
+        assert h.rng_fingerprint(capi.RNG_GLOBAL) == c.rng_fingerprint(capi.RNG_GLOBAL), f"tick {t}: RNG"
+        ch, cc = h.counters(), c.counters()
+        for f in ("parked", "live_through", "count_completed_through", "total_distance_through", "malfunctions",
+                  "created_service_food", "created_service_waste", "live_service_food", "live_service_waste", "astar_calls"):
+            assert getattr(ch, f) == getattr(cc, f), f"tick {t}: {f}"
+    assert own_cell_retargets > 20, "the scenario is built to exercise arrivals inside the decide phase"
+    assert raised is not None and raised[1] == capi.TS_E_UNSUPPORTED
+    h.close()
+    c.close()
