@@ -1,22 +1,60 @@
 #!/usr/bin/env python3
-"""Condense two rocprofv3 --pmc counter_collection.csv files (FETCH_SIZE run, WRITE_SIZE run) into
-profiles/r01_pmc_summary.json: per kernel, launches and average / max KB per launch."""
-import collections, csv, json, re, sys
+"""Condense rocprofv3 output (rocpd .db files, or the older counter_collection.csv) into the summaries committed
+under profiles/:
+
+  summarize_pmc.py stats  <kernel-trace results.db>  <out.csv>          per-kernel calls / total / avg / min / max (ns)
+  summarize_pmc.py pmc    <FETCH_SIZE run .db|.csv> <WRITE_SIZE run .db|.csv> <out.json>
+                                                                          per kernel: launches, avg / max KB per launch
+
+Collected with (separate runs, as MI355X_MICROARCH.md prescribes; `cd /tmp && export TMPDIR=/tmp` first):
+  rocprofv3 --kernel-trace --stats -d <dir> -o bench -- python3 bench.py --steps 50 --warmup 5
+  rocprofv3 --pmc FETCH_SIZE -d <dir> -o pmc -- python3 bench.py --steps 12 --warmup 3
+  rocprofv3 --pmc WRITE_SIZE -d <dir> -o pmc -- python3 bench.py --steps 12 --warmup 3
+"""
+import collections, csv, json, re, sqlite3, sys
+
+
+def short(name):
+    m = re.search(r"\b(k_[a-z_0-9]+)", name)
+    return m.group(1) if m else name
+
 
 def agg(path, counter):
     d = collections.defaultdict(list)
+    if path.endswith(".db"):
+        c = sqlite3.connect(path)
+        for name, val in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+            d[short(name)].append(float(val))
+        return d
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
-            continue
-        m = re.search(r"\b(k_[a-z_0-9]+)", r["Kernel_Name"])
-        d[m.group(1) if m else r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] == counter:
+            d[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return d
 
-f, w = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(f) | set(w)):
-    fv, wv = f.get(k, []), w.get(k, [])
-    out[k] = dict(launches=len(fv), fetch_kb_avg=sum(fv) / max(len(fv), 1), fetch_kb_max=max(fv) if fv else 0.0,
-                  write_kb_avg=sum(wv) / max(len(wv), 1), write_kb_max=max(wv) if wv else 0.0)
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if k.startswith("k_move") or k.startswith("k_decide")}, indent=1))
+
+def main():
+    if sys.argv[1] == "stats":
+        c = sqlite3.connect(sys.argv[2])
+        rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                         "group by name order by sum(duration) desc").fetchall()
+        total = sum(r[2] for r in rows)
+        with open(sys.argv[3], "w", newline="") as f:
+            w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                w.writerow([r[0], r[1], r[2], round(r[3], 3), round(100.0 * r[2] / total, 4), r[4], r[5]])
+        for r in rows[:8]:
+            print(f"{short(r[0]):24s} calls {r[1]:5d} avg {r[3] / 1e3:9.2f} us  total {r[2] / 1e6:8.2f} ms")
+        return
+    f, w = agg(sys.argv[2], "FETCH_SIZE"), agg(sys.argv[3], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(f) | set(w)):
+        fv, wv = f.get(k, []), w.get(k, [])
+        out[k] = dict(launches=len(fv), fetch_kb_avg=sum(fv) / max(len(fv), 1), fetch_kb_max=max(fv) if fv else 0.0,
+                      write_kb_avg=sum(wv) / max(len(wv), 1), write_kb_max=max(wv) if wv else 0.0)
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k.startswith("k_move") or k.startswith("k_decide")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

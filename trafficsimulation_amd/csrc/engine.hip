@@ -1078,6 +1078,11 @@ struct ts_engine {
   uint8_t *d_take = nullptr, *h_take = nullptr;   // take table of the stream range the next pass will walk
   size_t cap_take = 0;
   uint64_t take_guess = 0;
+  // the table for the NEXT tick is built right after this tick's decide phase (copy stream, overlapping the move
+  // phase): [take_base, take_base + take_n) in absolute stream positions, ready once take_ev has fired
+  uint64_t take_base = 0;
+  size_t take_n = 0;
+  hipEvent_t take_ev = nullptr;
   std::thread sh_thread, sh2_thread;
   std::atomic<int> sh_progress{0};   // draws extracted so far (shuffle pipeline)
   unsigned sh_gen = 0;
@@ -2018,15 +2023,24 @@ int tick(E* e) {
       // take table for the stretch of the stream this pass will most likely walk (estimate from the last pass;
       // positions beyond it fall back to the accept bitmask on the host)
       const uint64_t base = r.pos();
-      size_t n_take = (size_t)std::min<uint64_t>(e->cap_take, e->take_guess);
-      if (n_take > 0) {
-        if (e->words_uploaded < base + n_take + 64) n_take = e->words_uploaded > base + 64 ? (size_t)(e->words_uploaded - base - 64) : 0;
-      }
-      if (n_take > 0) {
-        HIPOK(hipStreamWaitEvent(st, e->words_ev, 0));
-        hipLaunchKernelGGL(k_rng_take, dim3(nblk((long long)n_take)), dim3(BLK), 0, st, d.words, (unsigned long long)base,
-                           (int)n_take, span, rshift, e->d_take);
-        HIPOK(hipMemcpyAsync(e->h_take, e->d_take, n_take, hipMemcpyDeviceToHost, st));
+      // the table built ahead of time covers [take_base, take_base + take_n); `toff` = where this pass starts in it
+      size_t n_take = 0, toff = 0;
+      if (e->take_n > 0 && base >= e->take_base && base - e->take_base + 4096 < e->take_n) {
+        toff = (size_t)(base - e->take_base);
+        n_take = e->take_n - toff;
+        HIPOK(hipEventSynchronize(e->take_ev));
+      } else {
+        n_take = (size_t)std::min<uint64_t>(e->cap_take, e->take_guess);
+        if (n_take > 0) {
+          if (e->words_uploaded < base + n_take + 64) n_take = e->words_uploaded > base + 64 ? (size_t)(e->words_uploaded - base - 64) : 0;
+        }
+        if (n_take > 0) {
+          HIPOK(hipStreamWaitEvent(st, e->words_ev, 0));
+          hipLaunchKernelGGL(k_rng_take, dim3(nblk((long long)n_take)), dim3(BLK), 0, st, d.words, (unsigned long long)base,
+                             (int)n_take, span, rshift, e->d_take);
+          HIPOK(hipMemcpyAsync(e->h_take, e->d_take, n_take, hipMemcpyDeviceToHost, st));
+        }
+        e->take_base = base; e->take_n = n_take;   // (valid once the sync below has passed)
       }
       const int guess = std::min(n, e->roll_guess);
       HIPOK(hipMemcpyAsync(e->hint + 4, d.cnt->rng_tot, sizeof(unsigned int) * 2, hipMemcpyDeviceToHost, st));
@@ -2045,7 +2059,7 @@ int tick(E* e) {
       // the rolls before it); the producer thread tabulated how many words a roll takes from any position.
       const double t_scan0 = now_ms();
       uint32_t* Tcum = e->h_Tcum;
-      const uint8_t* take_tab = e->h_take;
+      const uint8_t* take_tab = e->h_take + toff;
       const uint32_t* rollD = e->h_rollD;
       Tcum[0] = 0;
       {
@@ -2150,6 +2164,22 @@ int tick(E* e) {
     // prefetch the part of the stream the next tick will most likely read
     { const double t_wu = now_ms(); int rc = words_upload(e, r.pos() + (uint64_t)nA * 4 + (1u << 16)); if (rc) return rc;
       host_prof(e, PH_WORDS, now_ms() - t_wu, nA); }
+    {
+      // ... and build the next tick's take table behind that upload, on the copy stream: kernel and download
+      // overlap the move phase instead of sitting in front of the next host chain
+      const uint64_t nb = r.pos();
+      size_t nt = (size_t)std::min<uint64_t>(e->cap_take, e->take_guess);
+      if (e->words_uploaded < nb + nt + 64) nt = e->words_uploaded > nb + 64 ? (size_t)(e->words_uploaded - nb - 64) : 0;
+      e->take_n = 0;
+      static const bool ahead = !getenv("TS_NO_TAKE_AHEAD");
+      if (nt > 0 && ahead) {
+        hipLaunchKernelGGL(k_rng_take, dim3(nblk((long long)nt)), dim3(BLK), 0, e->copy_stream, d.words, (unsigned long long)nb,
+                           (int)nt, span, rshift, e->d_take);
+        HIPOK(hipMemcpyAsync(e->h_take, e->d_take, nt, hipMemcpyDeviceToHost, e->copy_stream));
+        HIPOK(hipEventRecord(e->take_ev, e->copy_stream));
+        e->take_base = nb; e->take_n = nt;
+      }
+    }
     if (e->hint[8] > 0) { int rc = run_replans(e, e->hint[8]); if (rc) return rc; }
     if (svc_on) {
       // on_target_reached inside step_decide for vehicles that stay on the grid (vehicle_base.py:657-661): apply the
@@ -2474,6 +2504,7 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   ok &= hipStreamCreate(&e->copy_stream) == hipSuccess;
   ok &= hipStreamCreateWithFlags(&e->perm_stream, hipStreamNonBlocking) == hipSuccess;
   ok &= hipEventCreateWithFlags(&e->perm_ev, hipEventDisableTiming) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&e->take_ev, hipEventDisableTiming) == hipSuccess;
   e->device = g_device;
   ok &= hipEventCreateWithFlags(&e->words_ev, hipEventDisableTiming) == hipSuccess;
   if (!ok) return bail(TS_E_DEVICE);
@@ -2500,6 +2531,7 @@ int ts_destroy(ts_handle e) {
   }
   if (e->perm_stream) { (void)hipStreamSynchronize(e->perm_stream); (void)hipStreamDestroy(e->perm_stream); }
   if (e->perm_ev) (void)hipEventDestroy(e->perm_ev);
+  if (e->take_ev) (void)hipEventDestroy(e->take_ev);
   for (void* p : e->allocs) (void)hipFree(p);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->hF) (void)hipHostFree(e->hF);
@@ -2710,13 +2742,13 @@ int ts_set_traffic_generator(ts_handle e, const TsTrafficTables* t) {
 int ts_seed(ts_handle e, int32_t stream, const uint32_t* mt, uint32_t index) {
   if (!e || !mt || stream < 0 || stream > 1 || index > 624) return TS_E_INVALID;
   (stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched).seed(mt, index);
-  if (stream == TS_RNG_GLOBAL) e->words_uploaded = e->rng_global.pos();
+  if (stream == TS_RNG_GLOBAL) { e->words_uploaded = e->rng_global.pos(); e->take_n = 0; }
   return TS_OK;
 }
 int ts_seed_int(ts_handle e, int32_t stream, uint64_t seed) {
   if (!e || stream < 0 || stream > 1) return TS_E_INVALID;
   (stream == TS_RNG_GLOBAL ? e->rng_global : e->rng_sched).seed_u64(seed);
-  if (stream == TS_RNG_GLOBAL) e->words_uploaded = e->rng_global.pos();
+  if (stream == TS_RNG_GLOBAL) { e->words_uploaded = e->rng_global.pos(); e->take_n = 0; }
   return TS_OK;
 }
 int ts_rng_state(ts_handle e, int32_t stream, uint32_t* mt_out, uint32_t* index_out) {
