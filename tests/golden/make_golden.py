@@ -96,6 +96,13 @@ SCENARIOS = {
                                            "PASSING_POPULATION_TRAFFIC_PER_DAY": 1500,
                                            "TOTAL_SERVICE_VEHICLES_FOOD": 600, "TOTAL_SERVICE_VEHICLES_WASTE": 600,
                                            "VEHICLE_MALFUNCTION_CHANCE": 0.002, "VEHICLE_MALFUNCTION_DURATION": 25}),
+    # config-5 style with every subsystem on: sub-block roads + L-shaped carves, traffic generator, service fleet,
+    # rain, queue-actuated lights, full replanning policy
+    "config5_96_s17": dict(size=96, seed=17, vehicles=60, ticks=300,
+                           defaults={"RAIN_RADIUS_MIN": 10, "RAIN_RADIUS_MAX": 25, "RAIN_SPAWN_CHANCE": 0.15,
+                                     "TOTAL_SERVICE_VEHICLES_FOOD": 200, "TOTAL_SERVICE_VEHICLES_WASTE": 200,
+                                     "INTERNAL_POPULATION_TRAFFIC_PER_DAY": 6000, "PASSING_POPULATION_TRAFFIC_PER_DAY": 2400},
+                           model_kwargs=dict(carve_subblock_roads=True)),
     # config 1 of BASELINE.json: everything on (rain, traffic generator, service vehicles, city blocks)
     "config1_64_s11": dict(size=64, seed=11, vehicles=50, ticks=500, defaults={}),
 }
