@@ -56,12 +56,15 @@ def make_workload(size, vehicles, seed):
 
 
 FULL_POLICY = {"RAIN_ENABLED": False}   # everything else at the reference's defaults (config.py)
+# BASELINE config 3's kernels without the searches: queue-actuated light groups stepping inside the shuffled order
+# (phase + intersection clearance), car-following and movement; replans gated off like config 2
+LIGHTS_POLICY = dict(POLICY, TRAFFIC_LIGHT_AGENT_ALGORITHM="QUEUE_ACTUATED")
 
 
 def setup(api, tables, routes, seed, extra=None, policy="config2"):
     from trafficsimulation_amd import _capi as capi
     from trafficsimulation_amd.world import build_engine
-    d = dict(POLICY if policy == "config2" else FULL_POLICY)
+    d = dict(POLICY if policy == "config2" else LIGHTS_POLICY if policy == "lights" else FULL_POLICY)
     d.update(extra or {})
     p = api.params_from_defaults(d)
     if extra and "eager_density" in extra:
@@ -80,7 +83,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--vehicles", type=int, default=1_000_000)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--policy", choices=["config2", "full"], default="config2",
+    ap.add_argument("--policy", choices=["config2", "lights", "full"], default="config2",
                     help="config2 = car-following + movement only (BASELINE config 2); full = reference defaults: "
                          "QUEUE_ACTUATED lights, replanning (GPU A*), contraflow, malfunctions (BASELINE config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,6 +169,9 @@ def main():
                 "workload": f"{args.size}x{args.size} synthetic city (citygen seed {args.seed}), {v0} vehicles per GPU, "
                             + ("config-2 policy: car-following + movement kernels, lights DISABLED, replans gated off, "
                                "malfunction/sideswipe chance 0; random-walk routes" if args.policy == "config2" else
+                               "lights policy: config 2 plus QUEUE_ACTUATED light groups (phase change, intersection "
+                               "clearance) stepping in the shuffled order; replans gated off; random-walk routes"
+                               if args.policy == "lights" else
                                "full policy: reference defaults (QUEUE_ACTUATED lights, GPU A* replanning, contraflow, "
                                "malfunctions/sideswipes), rain and spawning off; random-walk initial routes"),
                 "policy": args.policy,
