@@ -103,6 +103,11 @@ struct Dev {
   int32_t *g_light_off, *light_cell, *light_ctrl_off, *light_ctrl, *g_ns_off, *g_ns, *g_ew_off, *g_ew, *g_icell_off,
       *g_icell, *g_nsin_off, *g_nsin, *g_nsout_off, *g_nsout, *g_ewin_off, *g_ewin, *g_ewout_off, *g_ewout, *g_nb,
       *g_nb_ctor, *g_slot;
+  // every (cell, group, claim plane) pair a light group announces in the move phase, flattened so that the first
+  // round of a move phase claims them with one thread per pair instead of one thread walking a whole group
+  int32_t *gc_cell, *gc_group;
+  uint8_t* gc_plane;
+  int gc_n;
   int32_t *gs_cur, *gs_pend, *gs_trans, *gs_clear, *gs_ftphase, *gs_fttimer, *gs_qtimer, *gs_gap, *gs_last, *gs_nsp,
       *gs_ewp, *gs_repop;
   // per-cell min-rank claims for the move phase live in Cell::claim (epoch-tagged so they never need clearing)

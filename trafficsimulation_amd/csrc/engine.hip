@@ -149,7 +149,7 @@ __device__ __forceinline__ bool group_reads_neighbors(const TsParams& P) {
 // makes stale entries of earlier rounds lose and nothing has to be cleared.
 // `list` == nullptr: every schedule slot (first round); otherwise the slots left unresolved by the previous round.
 __global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix, const int32_t* list, const int* list_n,
-                             uint32_t rank_limit) {
+                             uint32_t rank_limit, int group_cells_elsewhere) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int s;
   if (list) { if (t >= *list_n) return; s = list[t]; } else { s = t; if (s >= n_sched) return; }
@@ -178,16 +178,18 @@ __global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix, co
     }
   } else if (kind == TS_AGENT_LIGHT_GROUP && P.light_algorithm != TS_LIGHTS_DISABLED) {
     const int g = d.sched_ref[s];
-    for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1]; k++) claim(d, d.g_icell[k], 1, key);
-    for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1]; k++) claim(d, d.g_nsin[k], 1, key);
-    for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1]; k++) claim(d, d.g_ewin[k], 1, key);
-    if (group_reads_out(P)) {
-      for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1]; k++) claim(d, d.g_nsout[k], 1, key);
-      for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1]; k++) claim(d, d.g_ewout[k], 1, key);
-    }
-    for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1]; l++) {
-      claim(d, d.light_cell[l], 2, key);
-      for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) claim(d, d.light_ctrl[k], 2, key);
+    if (!group_cells_elsewhere) {   // (the first round of a phase claims the cells in k_move_claim_groups)
+      for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1]; k++) claim(d, d.g_icell[k], 1, key);
+      for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1]; k++) claim(d, d.g_nsin[k], 1, key);
+      for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1]; k++) claim(d, d.g_ewin[k], 1, key);
+      if (group_reads_out(P)) {
+        for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1]; k++) claim(d, d.g_nsout[k], 1, key);
+        for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1]; k++) claim(d, d.g_ewout[k], 1, key);
+      }
+      for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1]; l++) {
+        claim(d, d.light_cell[l], 2, key);
+        for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) claim(d, d.light_ctrl[k], 2, key);
+      }
     }
     if (group_reads_neighbors(P)) {
       for (int k = 0; k < 4; k++) {
@@ -197,6 +199,16 @@ __global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix, co
       }
     }
   }
+}
+
+// the cell claims of every unresolved light group below the rank limit, one thread per (cell, group, plane) pair
+__global__ void k_move_claim_groups(Dev d, uint32_t prefix, uint32_t rank_limit) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= d.gc_n) return;
+  const int s = d.g_slot[d.gc_group[j]];
+  const uint32_t rk = d.rank[s];
+  if (d.resolved[s] || rk >= rank_limit) return;
+  atomicMin(&d.cell[d.gc_cell[j]].claim[d.gc_plane[j]], (prefix << RANK_BITS) | rk);
 }
 
 __device__ __forceinline__ void cell_unlink(const Dev& d, int cell, int vid) {
@@ -2357,8 +2369,10 @@ int tick(E* e) {
           const int32_t* in_list = round_no == 0 ? nullptr : e->pend_list[in];
           const int grid_items = round_no == 0 ? nS : pending_bound;
           HIPOK(hipMemsetAsync(&d.cnt->pend_n[out], 0, sizeof(int), st));
+          const int flat = round_no == 0 && d.gc_n > 0 && e->groups_scheduled == d.G && P.light_algorithm != TS_LIGHTS_DISABLED;
           LAUNCH(e, PK_MOVE_CLAIM, grid_items, k_move_claim, dim3(nblk(grid_items)), dim3(BLK), d, P, nS, prefix, in_list,
-                 &d.cnt->pend_n[in], rank_limit);
+                 &d.cnt->pend_n[in], rank_limit, flat);
+          if (flat) LAUNCH(e, PK_MOVE_CLAIM, d.gc_n, k_move_claim_groups, dim3(nblk(d.gc_n)), dim3(BLK), d, prefix, rank_limit);
           LAUNCH(e, PK_MOVE_RESOLVE, grid_items, k_move_resolve, dim3(nblk(grid_items)), dim3(BLK), d, P, nS, prefix,
                  rank_clock, elapsed0, in_list, &d.cnt->pend_n[in], e->pend_list[out], &d.cnt->pend_n[out], rank_limit);
           e->C.move_rounds++;
@@ -2591,6 +2605,34 @@ int ts_set_lights(ts_handle e, const TsLightTables* t) {
   UPOFF(g_ewout_off, g_ew_out_off, G + 1) UPCELLS(g_ewout, g_ew_out_xy, t->g_ew_out_off[G])
 #undef UPOFF
 #undef UPCELLS
+  {
+    // flat (cell, group, plane) list of everything a group claims in the move phase (k_move_claim_groups)
+    std::vector<int32_t> fc, fg;
+    std::vector<uint8_t> fp;
+    std::vector<int32_t> cidx;
+    const bool outs = e->P.light_algorithm == TS_LIGHTS_PRESSURE_CONTROL || e->P.light_algorithm == TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL;
+    auto add_range = [&](const int32_t* off, const int32_t* xy, int g, int plane) {
+      for (int k = off[g]; k < off[g + 1]; k++) { fc.push_back(xy[2 * k + 1] * W + xy[2 * k]); fg.push_back(g); fp.push_back((uint8_t)plane); }
+    };
+    for (int g = 0; g < G; g++) {
+      add_range(t->g_icell_off, t->g_icell_xy, g, 1);
+      add_range(t->g_ns_in_off, t->g_ns_in_xy, g, 1);
+      add_range(t->g_ew_in_off, t->g_ew_in_xy, g, 1);
+      if (outs) { add_range(t->g_ns_out_off, t->g_ns_out_xy, g, 1); add_range(t->g_ew_out_off, t->g_ew_out_xy, g, 1); }
+      for (int l = t->g_light_off[g]; l < t->g_light_off[g + 1]; l++) {
+        fc.push_back(t->light_xy[2 * l + 1] * W + t->light_xy[2 * l]); fg.push_back(g); fp.push_back(2);
+        add_range(t->light_ctrl_off, t->light_ctrl_xy, l, 2);
+        for (size_t q = fg.size() - (size_t)(t->light_ctrl_off[l + 1] - t->light_ctrl_off[l]); q < fg.size(); q++) fg[q] = g;
+      }
+    }
+    d.gc_n = (int)fc.size();
+    HIPOK(dalloc(e, &d.gc_cell, fc.size())); HIPOK(dalloc(e, &d.gc_group, fg.size())); HIPOK(dalloc(e, &d.gc_plane, fp.size()));
+    if (!fc.empty()) {
+      HIPOK(hipMemcpy(d.gc_cell, fc.data(), fc.size() * 4, hipMemcpyHostToDevice));
+      HIPOK(hipMemcpy(d.gc_group, fg.data(), fg.size() * 4, hipMemcpyHostToDevice));
+      HIPOK(hipMemcpy(d.gc_plane, fp.data(), fp.size(), hipMemcpyHostToDevice));
+    }
+  }
   std::vector<int32_t> nb((size_t)G * 8, -1), nbc((size_t)G * 8, -1);
   if (t->g_neighbors) nb.assign(t->g_neighbors, t->g_neighbors + (size_t)G * 8);
   const int32_t* nc = t->g_neighbors_ctor ? t->g_neighbors_ctor : t->g_neighbors;
