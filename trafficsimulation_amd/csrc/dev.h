@@ -140,7 +140,12 @@ __device__ __forceinline__ bool seen_stranded(const Dev& d, int ag, int my_idx) 
   if (e) {  // stranded by a malfunction / sideswipe found during this tick's decide phase, at order index j
     const int j = d.ev_idx[ag];
     if (e == 1) return j < my_idx ? true : (d.st_before[ag] != 0);  // the vehicle that drew the event (j = its own index)
-    return j < my_idx;                                                // its partner: a valid candidate, so fine until then
+    if (j < my_idx) return true;                                      // its partner, seen after the collision
+    // ... seen before the collision.  A later partner (3) was a valid candidate when it was hit, i.e. not stranded
+    // before its own turn (and its st_before has been re-derived from the post-collision flags since: not usable).
+    if (e == 3) return false;
+    // An earlier partner (2) was not stranded after its own step_decide, but may have carried an old stranding into
+    // it that only expired there: observers ahead of it still saw that (its st_before / st_after predate the event).
   }
   if (d.active_idx[ag] < my_idx) return d.st_after[ag] != 0;
   return d.st_before[ag] != 0;

@@ -291,7 +291,12 @@ __device__ __forceinline__ void vehicle_step_dev(const Dev& d, const TsParams& P
         if (go && k < m && k < plen) {
           const int nc = cells[k + 1];
           const uint32_t dw = dyn[k + 1].y;   // occ | stop << 8 | stuck << 16 | stat << 24
-          const int occ = (int8_t)(dw & 0xFF), stop = (int8_t)((dw >> 8) & 0xFF);
+          int occ = (int8_t)(dw & 0xFF);
+          const int stop = (int8_t)((dw >> 8) & 0xFF);
+          // the record was read before this vehicle started to move: a cell it has itself left in the meantime
+          // (a route may loop back through it) is free now - leaving clears the byte whoever else stands there
+#pragma unroll
+          for (int j = 0; j < MOVE_MAX; j++) if (j < k && cells[j] == nc) occ = 0;
           if (occ == 1 || (stop == 1 && k != m - 1)) go = false;
           else {
             set_occ(d, c, 0); set_occ(d, nc, 1);
