@@ -90,10 +90,11 @@ def run_case(case, make_engines, ticks=45):
 
 
 N_CASES = int(os.environ.get("TS_RANDOM_CASES", "20"))   # more for a bug hunt: TS_RANDOM_CASES=200 TS_RANDOM_TICKS=80
+FIRST = int(os.environ.get("TS_RANDOM_FIRST", "0"))
 N_TICKS = int(os.environ.get("TS_RANDOM_TICKS", "45"))
 
 
-@pytest.mark.parametrize("case", range(N_CASES))
+@pytest.mark.parametrize("case", range(FIRST, FIRST + N_CASES))
 def test_hip_vs_oracle_random_config(case):
     from oracle import pyoracle
     from trafficsimulation_amd._lib import new_engine
