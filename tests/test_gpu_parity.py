@@ -216,3 +216,34 @@ def test_hip_vs_oracle_service_stress():
     assert raised is not None and raised[1] == capi.TS_E_UNSUPPORTED
     h.close()
     c.close()
+
+
+def test_hip_multi_pass_decide_in_a_subprocess():
+    """More vehicles than one RNG pass covers (2^20) split the decide phase into several passes, each resuming the
+    stream bookkeeping where the previous one stopped.  TS_DEBUG_SEG shrinks the pass size so that a 256x256 world
+    walks that path (dozens of passes per tick, with strandings firing inside them); the knob is read once per
+    process, hence the subprocess."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, '.')\n"
+        "from tests.test_gpu_parity import _pair, _compare\n"
+        "pol = {'TRAFFIC_LIGHT_AGENT_ALGORITHM': 'QUEUE_ACTUATED', 'VEHICLE_MALFUNCTION_CHANCE': 0.002,\n"
+        "       'VEHICLE_MALFUNCTION_DURATION': 12, 'VEHICLE_SIDESWIPE_COLLISION_CHANCE': 0.05,\n"
+        "       'VEHICLE_SIDESWIPE_COLLISION_DURATION': 9, 'PATHFINDING_COOLDOWN': 4}\n"
+        "h, c = _pair(256, 6000, 11, pol)\n"
+        "_compare(h, c, 30)\n"
+        "print('multi-pass ok')\n")
+    env = dict(os.environ, TS_DEBUG_SEG="777")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "multi-pass ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_hip_vs_oracle_long_run_word_ring_wraps():
+    """400 ticks at 512x512 / 50k vehicles consume ~50M words of the global stream and ~20M of the scheduler stream:
+    both pre-generated word rings (8M words each) and the device mirror wrap several times, the move-phase claim
+    epochs wrap too."""
+    h, c = _pair(512, 50_000, 21, {"TRAFFIC_LIGHT_AGENT_ALGORITHM": "QUEUE_ACTUATED"})
+    _compare(h, c, 400, every=25)

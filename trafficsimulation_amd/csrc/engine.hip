@@ -2021,7 +2021,9 @@ int tick(E* e) {
     const uint32_t span = (uint32_t)(P.vehicle_max_speed - P.vehicle_min_speed + 1);
     const int rshift = __builtin_clz(span);  // getrandbits(span.bit_length())
     MTPipe& r = e->rng_global;
-    const int SEG = 1 << 20;  // vehicles per pass (bounds the look-ahead into the word ring)
+    // vehicles per pass (bounds the look-ahead into the word ring); TS_DEBUG_SEG shrinks it so that tests can walk
+    // the multi-pass path on small worlds
+    static const int SEG = getenv("TS_DEBUG_SEG") ? std::max(64, atoi(getenv("TS_DEBUG_SEG"))) : (1 << 20);
     int start = 0;
     bool main_done = false;
     LAUNCH(e, PK_DECIDE_PRE, nA, k_decide_pre, dim3(nblk(nA)), dim3(BLK), d, P, 0, nA);
