@@ -36,7 +36,7 @@ struct DevCnt {
   int deaths;      // vehicles removed this tick
   int arr_n;       // service records written this tick (Dev::arr)
   int error;       // sticky device-side error
-  int replan_n[6]; // work-list lengths: first tier, second, third, pool-full retries, beyond the last tier, LDS-tier overflow
+  int replan_n[8]; // work-list lengths, see run_replans (engine.hip)
   unsigned long long pool_used;  // words handed out from the path pool (device-side bump allocator)
   long long astar_calls, astar_exp, astar_relax;
   int pend_n[2];   // lengths of the two ping-pong lists of still-unresolved schedule slots

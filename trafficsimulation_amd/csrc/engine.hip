@@ -1114,10 +1114,11 @@ struct ts_engine {
   std::vector<void*> allocs;
   // per-kernel HIP-event timing (ts_profile_*)
   // replanning: work lists, scratch tiers, density state, host-side _path_cache
-  int32_t* replan_list[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [4] = input of the LDS tier
+  int32_t* replan_list[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // see run_replans
   int cap_replan = 0;
-  ATier tier[3];
-  bool tier_ready[3] = {false, false, false};
+  static constexpr int N_TIERS = 4;
+  ATier tier[N_TIERS];
+  bool tier_ready[N_TIERS] = {false, false, false, false};
   bool density_valid = false;
   float *dens_t0 = nullptr, *dens_t1 = nullptr;
   int32_t* d_status = nullptr;
@@ -1226,6 +1227,7 @@ int ensure_vehicle_capacity(E* e, int need_v, int need_sched) {
     { int rc = regrow(e, &e->replan_list[2], 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &e->replan_list[3], 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &e->replan_list[4], 0, (size_t)nc); if (rc) return rc; }
+    { int rc = regrow(e, &e->replan_list[5], 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &d.active, (size_t)e->n_active, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &e->active_alt, 0, (size_t)nc); if (rc) return rc; }
     { int rc = regrow(e, &d.F, 0, (size_t)nc); if (rc) return rc; }
@@ -1341,8 +1343,13 @@ int ensure_tier(E* e, int t) {
   if (e->tier_ready[t]) return TS_OK;
   ATier& T = e->tier[t];
   const long long N = e->N;
-  const long long caps[3] = {std::min<long long>(N, 2048), std::min<long long>(N, 32768), N};
-  const int slots[3] = {16384, 1024, 4};
+  // nodes a search may touch per tier: 2048 / 32 768 / 262 144 / the whole map; the smaller a search's footprint,
+  // the more of them run side by side.  The last tier gets as many slots as ~16 GB of scratch allow (4 .. 64).
+  const long long caps[ts_engine::N_TIERS] = {std::min<long long>(N, 2048), std::min<long long>(N, 32768),
+                                              std::min<long long>(N, 262144), N};
+  const long long last_bytes = N * (2 * 16 + 4 * 17 + 5 * 4);   // table + heap + dir bytes + five cell buffers, per slot
+  const int last_slots = (int)std::max<long long>(4, std::min<long long>(64, (16ll << 30) / std::max<long long>(last_bytes, 1)));
+  const int slots[ts_engine::N_TIERS] = {16384, 1024, 128, last_slots};
   T.cap = (int)caps[t];
   T.n_slots = slots[t];
   uint32_t hs = 1;
@@ -1434,11 +1441,13 @@ int run_replans(E* e, int n0) {
                e->bfs_queue, words_per, queue_per);
       }
     }
-    // stage 0: search structures in LDS (one wave per vehicle); stages 1-3: the HBM tiers for what outgrows it
+    // stage 0: search structures in LDS (one wave per vehicle); stages 1-4: the HBM tiers for what outgrows it.
+    // Lists: 0 = input, 4 = LDS overflow, 1 / 2 / 5 = overflow of the first three HBM tiers, 3 = pool-full retries.
+    // Counters (replan_n): 5, 1, 2, 6 for those overflow lists, 4 = beyond the last tier (an error), 3 = retries.
     struct Stage { int tier; int in_list; int out_list; int out_counter; };
-    const Stage stages[4] = {{-1, 0, 4, 5}, {0, 4, 1, 1}, {1, 1, 2, 2}, {2, 2, 3, 4}};
+    const Stage stages[5] = {{-1, 0, 4, 5}, {0, 4, 1, 1}, {1, 1, 2, 2}, {2, 2, 5, 6}, {3, 5, 3, 4}};
     int n = n0;
-    for (int sidx = 0; sidx < 4 && n > 0; sidx++) {
+    for (int sidx = 0; sidx < 5 && n > 0; sidx++) {
       const Stage& sg = stages[sidx];
       const int t = sg.tier < 0 ? 0 : sg.tier;   // the LDS stage borrows the first tier's cell buffers
       int rc = ensure_tier(e, t);
@@ -1453,7 +1462,7 @@ int run_replans(E* e, int n0) {
           LAUNCH(e, PK_REPLAN, cnt, k_decide_replan, dim3(nblk(cnt, 64)), dim3(64), d, P, T, e->replan_list[sg.in_list], begin,
                  cnt, e->replan_list[sg.out_list], sg.out_counter, e->replan_list[3]);
       }
-      HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+      HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
       HIPOK(hipStreamSynchronize(st));
       if (e->hint[8 + 4] > 0) return fail(e, TS_E_CAPACITY, "an A* search exceeded the largest scratch tier");
       if (getenv("TS_DEBUG_REPLAN")) {
@@ -1463,7 +1472,7 @@ int run_replans(E* e, int n0) {
         tlast = tn;
       }
       n = e->hint[8 + sg.out_counter];
-      if (sidx == 3) n = 0;
+      if (sidx == 4) n = 0;
     }
     int retry = e->hint[8 + 3];
     if (retry == 0) break;
@@ -1471,7 +1480,7 @@ int run_replans(E* e, int n0) {
     int rc = pool_make_room(e, (size_t)retry * 1024 + (1u << 20));
     if (rc) return rc;
     HIPOK(hipMemcpyAsync(e->replan_list[0], e->replan_list[3], (size_t)retry * 4, hipMemcpyDeviceToDevice, st));
-    HIPOK(hipMemsetAsync(d.cnt->replan_n, 0, sizeof(int) * 6, st));
+    HIPOK(hipMemsetAsync(d.cnt->replan_n, 0, sizeof(int) * 8, st));
     n0 = retry;
   }
   return TS_OK;
@@ -2010,7 +2019,7 @@ int tick(E* e) {
   // ---------------- decide ----------------
   if (nA > 0) {
     HIPOK(hipMemsetAsync(d.ev, 0, (size_t)e->n_vehicles_total, st));
-    HIPOK(hipMemsetAsync(d.cnt->replan_n, 0, sizeof(int) * 6, st));
+    HIPOK(hipMemsetAsync(d.cnt->replan_n, 0, sizeof(int) * 8, st));
     // random() < c  <=>  the 53-bit integer (a << 26 | b) < ceil(c * 2^53)   (exact: power-of-two scaling)
     auto thr53 = [](double c) -> unsigned long long {
       if (!(c > 0.0)) return 0;
@@ -2142,7 +2151,7 @@ int tick(E* e) {
         }
         if (seg_end == nA) {  // k_decide_main returns at once if a draw fired (the fix-up below re-runs it)
           LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, e->replan_list[0]);
-          HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+          HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
         }
         HIPOK(hipMemcpyAsync(e->hint + 6, &d.cnt->rng_event, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
         const double t_w3 = now_ms();
@@ -2177,7 +2186,7 @@ int tick(E* e) {
     if (!main_done) {  // the last pass ended with an event at the very last vehicle (or there was no pass left)
       HIPOK(hipMemsetAsync(&d.cnt->rng_event, 0xFF, sizeof(unsigned int), st));
       LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, e->replan_list[0]);
-      HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+      HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
       HIPOK(hipStreamSynchronize(st));
     }
     // prefetch the part of the stream the next tick will most likely read
@@ -2909,7 +2918,7 @@ static int plan_vehicle(ts_handle e, int vid, int start, int goal) {
     }
   }
   if (!e->density_valid) { rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
-  for (int t = 0; t < 3; t++) {
+  for (int t = 0; t < ts_engine::N_TIERS; t++) {
     rc = ensure_tier(e, t);
     if (rc) return rc;
     for (int attempt = 0; attempt < 3; attempt++) {
@@ -3213,7 +3222,7 @@ int ts_astar(ts_handle e, int32_t sx, int32_t sy, int32_t gx, int32_t gy, int32_
   int rc = ensure_density(e, e->d.occ);  // "evaluated on the engine's current maps"
   if (rc) return rc;
   e->density_valid = false;
-  for (int t = 0; t < 3; t++) {
+  for (int t = 0; t < ts_engine::N_TIERS; t++) {
     rc = ensure_tier(e, t);
     if (rc) return rc;
     hipLaunchKernelGGL(k_astar_single, dim3(1), dim3(64), 0, e->stream, e->d, e->P, e->tier[t], sy * e->W + sx,
