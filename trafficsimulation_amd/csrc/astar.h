@@ -40,8 +40,20 @@ struct AScratch {
   int node_cap;   // distinct cells the table may hold
   uint32_t epoch;
   int nodes;
+  int peak_nodes;   // largest table population any search of this vehicle reached (for the tier hint)
   long long calls, expansions, relaxations;
 };
+struct RLists { int32_t* l[6]; };       // replan work lists, see run_replans (engine.hip)
+struct StageCaps { int nodes[5]; };     // node capacity of each replanning stage
+// work list / counter a vehicle waiting for stage h is queued on
+__device__ __forceinline__ int stage_list(int h) { return h == 0 ? 0 : h == 1 ? 4 : h == 2 ? 1 : h == 3 ? 2 : 5; }
+__device__ __forceinline__ int stage_counter(int h) { return h == 0 ? 0 : h == 1 ? 5 : h == 2 ? 1 : h == 3 ? 2 : 6; }
+__device__ __forceinline__ void note_tier(const Dev& d, const AScratch& S, int vid, int stage, const StageCaps& caps) {
+  if (S.calls == 0) return;
+  int h = stage;
+  while (h > 0 && 2 * S.peak_nodes <= caps.nodes[h - 1]) h--;
+  d.tier_hint[vid] = (uint8_t)h;
+}
 
 struct ATier {
   int cap, n_slots, heap_cap;
@@ -65,6 +77,7 @@ __device__ __forceinline__ void scratch_bind(const ATier& t, int slot, AScratch&
   S.cap = t.cap;
   S.node_cap = t.cap;
   S.epoch = t.slot_epoch[slot];
+  S.peak_nodes = 0;
   S.nodes = 0; S.calls = 0; S.expansions = 0; S.relaxations = 0;
 }
 
@@ -198,6 +211,7 @@ __device__ int astar_dev(const Dev& d, const TsParams& P, AScratch& S, int start
         if (!found) {
           if (S.nodes >= S.node_cap) return -1;
           S.nodes++;
+          if (S.nodes > S.peak_nodes) S.peak_nodes = S.nodes;
         }
         S.ht[h] = HEnt{nidx, (int)ng, cur, S.epoch};
         if (heap_size >= S.heap_cap) return -1;
@@ -643,17 +657,20 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
 }
 
 // every live vehicle: the part of step_decide that needs no search; the others go to the replan list
-__global__ void k_decide_main(Dev d, TsParams P, int n_active, int32_t* replan_list) {
+__global__ void k_decide_main(Dev d, TsParams P, int n_active, RLists lists) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_active) return;
   if (d.cnt->rng_event != 0xFFFFFFFFu) return;  // a malfunction / sideswipe fired: the host re-runs this after the fix-up
-  if (decide_vehicle(d, P, i, nullptr) == DV_DEFER) replan_list[atomicAdd(&d.cnt->replan_n[0], 1)] = i;
+  if (decide_vehicle(d, P, i, nullptr) == DV_DEFER) {
+    const int h = min((int)d.tier_hint[d.active[i]], 4);   // start where its last search fitted
+    lists.l[stage_list(h)][atomicAdd(&d.cnt->replan_n[stage_counter(h)], 1)] = i;
+  }
 }
 
 // replanning vehicles: one lane per vehicle, private scratch from tier `t`.  Entries that outgrow the tier go
 // to `next_list` (counter replan_n[next_counter]); entries that find the pool full go to `retry_list`.
 __global__ void k_decide_replan(Dev d, TsParams P, ATier t, const int32_t* list, int begin, int n, int32_t* next_list,
-                                int next_counter, int32_t* retry_list) {
+                                int next_counter, int32_t* retry_list, int stage, StageCaps caps) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   AScratch S;
@@ -662,6 +679,7 @@ __global__ void k_decide_replan(Dev d, TsParams P, ATier t, const int32_t* list,
   int r = decide_vehicle(d, P, i, &S);
   t.slot_epoch[j] = S.epoch;
   if (r == DV_DONE) {  // work of attempts that are re-run on a larger tier / after pool growth is not counted twice
+    note_tier(d, S, d.active[i], stage, caps);
     atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
     atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
     atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
@@ -675,7 +693,8 @@ __global__ void k_decide_replan(Dev d, TsParams P, ATier t, const int32_t* list,
 // and LDS answers several times faster than L2.  Searches that outgrow the LDS budget go to the HBM tiers.
 constexpr int LDS_NODES = 1024, LDS_HASH = 2048, LDS_HEAP = 2048;
 __global__ void __launch_bounds__(64) k_decide_replan_lds(Dev d, TsParams P, ATier cells_tier, const int32_t* list, int begin,
-                                                            int n, int32_t* next_list, int next_counter, int32_t* retry_list) {
+                                                            int n, int32_t* next_list, int next_counter, int32_t* retry_list,
+                                                            StageCaps caps) {
   __shared__ HEnt s_ht[LDS_HASH];
   __shared__ QEnt s_hq[LDS_HEAP];
   __shared__ int8_t s_hd[LDS_HEAP];
@@ -688,10 +707,12 @@ __global__ void __launch_bounds__(64) k_decide_replan_lds(Dev d, TsParams P, ATi
   scratch_bind(cells_tier, j, S);   // cell buffers (paths) from the arena of the first HBM tier
   S.ht = s_ht; S.hmask = LDS_HASH - 1; S.hq = s_hq; S.hd = s_hd; S.heap_cap = LDS_HEAP;
   S.node_cap = LDS_NODES;
+  S.peak_nodes = 0;
   S.epoch = 0;
   const int i = list[begin + j];
   int r = decide_vehicle(d, P, i, &S);
   if (r == DV_DONE) {
+    note_tier(d, S, d.active[i], 0, caps);
     atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
     atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
     atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);

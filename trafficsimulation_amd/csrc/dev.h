@@ -86,6 +86,7 @@ struct Dev {
   uint32_t* ax_off[4];
   int32_t* ax_len[4];
   uint8_t* reach;    // per vehicle, this tick: 0 = unknown, 1 = target reachable under strict rules, 2 = not
+  uint8_t* tier_hint;  // per vehicle: the replanning stage (0 = LDS, 1.. = HBM tiers) its last search fitted in
   float* density;    // _update_density_map (city_model.py:1764-1778), materialised on demand
   int8_t* occ_snap;  // occupancy at the last tick start (what density_map is a function of)
   // ordered lists

@@ -675,7 +675,7 @@ __global__ void k_spawn(Dev d, TsParams P, SpawnArgs a, int n, int vid0, int act
   d.over_dur[vid] = -1; d.det_dur[vid] = -1; d.next_in_cell[vid] = -1;
   d.base_speed[vid] = 0; d.cur_speed[vid] = 0; d.max_steps[vid] = 0; d.dir[vid] = -1; d.pop[vid] = (int8_t)a.pop[i];
   d.flags[vid] = VF_ALIVE; d.depart[vid] = P.enable_traffic ? elapsed : 0.0;
-  d.ev[vid] = 0; d.st_before[vid] = 0; d.st_after[vid] = 0;
+  d.ev[vid] = 0; d.st_before[vid] = 0; d.st_after[vid] = 0; d.tier_hint[vid] = 0;
   for (int k = 0; k < 4; k++) { d.ax_len[k][vid] = 0; d.ax_off[k][vid] = 0; d.ax_start[k][vid] = pos; }
   d.active[active0 + i] = vid; d.active_idx[vid] = active0 + i;
   d.sched_kind[sched0 + i] = K_VEHICLE; d.sched_ref[sched0 + i] = vid; d.sched_slot[vid] = sched0 + i;
@@ -1219,7 +1219,7 @@ int ensure_vehicle_capacity(E* e, int need_v, int need_sched) {
 #define RG(field) { int rc = regrow(e, &d.field, k, (size_t)nc); if (rc) return rc; }
     RG(pos) RG(target) RG(path_len) RG(path_cur) RG(stuck_ticks) RG(cooldown) RG(stranded_left) RG(steps) RG(over_dur)
     RG(det_dur) RG(next_in_cell) RG(active_idx) RG(sched_slot) RG(path_off) RG(base_speed) RG(cur_speed) RG(max_steps)
-    RG(dir) RG(pop) RG(flags) RG(depart) RG(ev) RG(st_before) RG(st_after) RG(ev_idx) RG(reach)
+    RG(dir) RG(pop) RG(flags) RG(depart) RG(ev) RG(st_before) RG(st_after) RG(ev_idx) RG(reach) RG(tier_hint)
     for (int k = 0; k < 4; k++) { RG(ax_start[k]) RG(ax_off[k]) RG(ax_len[k]) }
 #undef RG
     { int rc = regrow(e, &e->replan_list[0], 0, (size_t)nc); if (rc) return rc; }
@@ -1419,13 +1419,28 @@ int pool_make_room(E* e, size_t need_free) {
   return TS_OK;
 }
 
-// k_decide_replan over the work lists: tier 0 -> overflow to tier 1 -> tier 2; pool-full entries are retried
 inline double now_ms();
-int run_replans(E* e, int n0) {
+// k_decide_replan over the work lists.  Stage 0 keeps the search structures in LDS (one wave per vehicle), stages
+// 1-4 are the HBM tiers; a search that outgrows its stage moves to the next one, and k_decide_main queues every
+// vehicle directly on the stage its last search fitted in (Dev::tier_hint).
+// Lists: 0 / 4 / 1 / 2 / 5 = input of stages 0..4, 3 = pool-full retries.  Counters (replan_n): 0 / 5 / 1 / 2 / 6 for
+// those inputs, 3 = retries, 4 = beyond the last tier (an error).
+struct ReplanStage { int tier; int in_list; int in_counter; int out_list; int out_counter; };
+static const ReplanStage REPLAN_STAGES[5] = {{-1, 0, 0, 4, 5}, {0, 4, 5, 1, 1}, {1, 1, 1, 2, 2}, {2, 2, 2, 5, 6}, {3, 5, 6, 3, 4}};
+inline int replan_pending(const int* n8) { return n8[0] + n8[5] + n8[1] + n8[2] + n8[6]; }
+
+int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   Dev& d = e->d;
   const TsParams& P = e->P;
   hipStream_t st = e->stream;
-  while (n0 > 0) {
+  StageCaps caps;
+  caps.nodes[0] = LDS_NODES;
+  {
+    const long long N = e->N;
+    const long long c[4] = {std::min<long long>(N, 2048), std::min<long long>(N, 32768), std::min<long long>(N, 262144), N};
+    for (int t = 0; t < 4; t++) caps.nodes[t + 1] = (int)c[t];
+  }
+  while (replan_pending(e->hint + 8) > 0) {
     if (!e->density_valid) { int rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
     {  // strict reachability of every replanner's target (skips the searches that would flood and fail)
       const size_t words_per = ((size_t)e->N + 31) / 32, queue_per = (size_t)e->N;
@@ -1435,20 +1450,19 @@ int run_replans(E* e, int n0) {
         HIPOK(dalloc(e, &e->bfs_visited, words_per * e->bfs_slots));
         HIPOK(dalloc(e, &e->bfs_queue, queue_per * e->bfs_slots));
       }
-      for (int begin = 0; begin < n0; begin += e->bfs_slots) {
-        int cnt = std::min(e->bfs_slots, n0 - begin);
-        LAUNCH(e, PK_REACH, cnt, k_reach_strict, dim3(cnt), dim3(64), d, e->replan_list[0] + begin, cnt, e->bfs_visited,
-               e->bfs_queue, words_per, queue_per);
+      for (const ReplanStage& sg : REPLAN_STAGES) {
+        const int n_in = e->hint[8 + sg.in_counter];
+        for (int begin = 0; begin < n_in; begin += e->bfs_slots) {
+          int cnt = std::min(e->bfs_slots, n_in - begin);
+          LAUNCH(e, PK_REACH, cnt, k_reach_strict, dim3(cnt), dim3(64), d, e->replan_list[sg.in_list] + begin, cnt, e->bfs_visited,
+                 e->bfs_queue, words_per, queue_per);
+        }
       }
     }
-    // stage 0: search structures in LDS (one wave per vehicle); stages 1-4: the HBM tiers for what outgrows it.
-    // Lists: 0 = input, 4 = LDS overflow, 1 / 2 / 5 = overflow of the first three HBM tiers, 3 = pool-full retries.
-    // Counters (replan_n): 5, 1, 2, 6 for those overflow lists, 4 = beyond the last tier (an error), 3 = retries.
-    struct Stage { int tier; int in_list; int out_list; int out_counter; };
-    const Stage stages[5] = {{-1, 0, 4, 5}, {0, 4, 1, 1}, {1, 1, 2, 2}, {2, 2, 5, 6}, {3, 5, 3, 4}};
-    int n = n0;
-    for (int sidx = 0; sidx < 5 && n > 0; sidx++) {
-      const Stage& sg = stages[sidx];
+    for (int sidx = 0; sidx < 5; sidx++) {
+      const ReplanStage& sg = REPLAN_STAGES[sidx];
+      const int n = e->hint[8 + sg.in_counter];   // hinted entries plus what the previous stage overflowed
+      if (n <= 0) continue;
       const int t = sg.tier < 0 ? 0 : sg.tier;   // the LDS stage borrows the first tier's cell buffers
       int rc = ensure_tier(e, t);
       if (rc) return rc;
@@ -1457,31 +1471,28 @@ int run_replans(E* e, int n0) {
         int cnt = std::min(T.n_slots, n - begin);
         if (sg.tier < 0)
           LAUNCH(e, PK_REPLAN, cnt, k_decide_replan_lds, dim3(cnt), dim3(64), d, P, T, e->replan_list[sg.in_list], begin, cnt,
-                 e->replan_list[sg.out_list], sg.out_counter, e->replan_list[3]);
+                 e->replan_list[sg.out_list], sg.out_counter, e->replan_list[3], caps);
         else
           LAUNCH(e, PK_REPLAN, cnt, k_decide_replan, dim3(nblk(cnt, 64)), dim3(64), d, P, T, e->replan_list[sg.in_list], begin,
-                 cnt, e->replan_list[sg.out_list], sg.out_counter, e->replan_list[3]);
+                 cnt, e->replan_list[sg.out_list], sg.out_counter, e->replan_list[3], sidx, caps);
       }
+      const double tl = now_ms();
       HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
       HIPOK(hipStreamSynchronize(st));
       if (e->hint[8 + 4] > 0) return fail(e, TS_E_CAPACITY, "an A* search exceeded the largest scratch tier");
-      if (getenv("TS_DEBUG_REPLAN")) {
-        static double tlast = 0; double tn = now_ms();
-        fprintf(stderr, "[replan] tick %lld stage %d: in=%d overflow=%d retry=%d dt=%.2f ms\n", (long long)e->C.step_count, sidx, n,
-                e->hint[8 + sg.out_counter], e->hint[8 + 3], tlast ? tn - tlast : 0.0);
-        tlast = tn;
-      }
-      n = e->hint[8 + sg.out_counter];
-      if (sidx == 4) n = 0;
+      if (getenv("TS_DEBUG_REPLAN"))
+        fprintf(stderr, "[replan] tick %lld stage %d: in=%d overflow=%d retry=%d wait=%.2f ms\n", (long long)e->C.step_count, sidx, n,
+                sidx < 4 ? e->hint[8 + sg.out_counter] - 0 : 0, e->hint[8 + 3], now_ms() - tl);
     }
-    int retry = e->hint[8 + 3];
+    const int retry = e->hint[8 + 3];
     if (retry == 0) break;
     // the path pool filled up: make room (GC, then growth) and run the entries that could not commit again
     int rc = pool_make_room(e, (size_t)retry * 1024 + (1u << 20));
     if (rc) return rc;
     HIPOK(hipMemcpyAsync(e->replan_list[0], e->replan_list[3], (size_t)retry * 4, hipMemcpyDeviceToDevice, st));
     HIPOK(hipMemsetAsync(d.cnt->replan_n, 0, sizeof(int) * 8, st));
-    n0 = retry;
+    for (int q = 0; q < 8; q++) e->hint[8 + q] = 0;
+    e->hint[8] = retry;
   }
   return TS_OK;
 }
@@ -2030,6 +2041,8 @@ int tick(E* e) {
     const uint32_t span = (uint32_t)(P.vehicle_max_speed - P.vehicle_min_speed + 1);
     const int rshift = __builtin_clz(span);  // getrandbits(span.bit_length())
     MTPipe& r = e->rng_global;
+    RLists rlists;
+    for (int q = 0; q < 6; q++) rlists.l[q] = e->replan_list[q];
     // vehicles per pass (bounds the look-ahead into the word ring); TS_DEBUG_SEG shrinks it so that tests can walk
     // the multi-pass path on small worlds
     static const int SEG = getenv("TS_DEBUG_SEG") ? std::max(64, atoi(getenv("TS_DEBUG_SEG"))) : (1 << 20);
@@ -2150,7 +2163,7 @@ int tick(E* e) {
           prof_end(e, tok);
         }
         if (seg_end == nA) {  // k_decide_main returns at once if a draw fired (the fix-up below re-runs it)
-          LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, e->replan_list[0]);
+          LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, rlists);
           HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
         }
         HIPOK(hipMemcpyAsync(e->hint + 6, &d.cnt->rng_event, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
@@ -2185,7 +2198,7 @@ int tick(E* e) {
     }
     if (!main_done) {  // the last pass ended with an event at the very last vehicle (or there was no pass left)
       HIPOK(hipMemsetAsync(&d.cnt->rng_event, 0xFF, sizeof(unsigned int), st));
-      LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, e->replan_list[0]);
+      LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, rlists);
       HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
       HIPOK(hipStreamSynchronize(st));
     }
@@ -2208,7 +2221,7 @@ int tick(E* e) {
         e->take_base = nb; e->take_n = nt;
       }
     }
-    if (e->hint[8] > 0) { int rc = run_replans(e, e->hint[8]); if (rc) return rc; }
+    if (replan_pending(e->hint + 8) > 0) { int rc = run_replans(e); if (rc) return rc; }
     if (svc_on) {
       // on_target_reached inside step_decide for vehicles that stay on the grid (vehicle_base.py:657-661): apply the
       // flag changes now that no decider can see them half-way, then the host part in decide order
