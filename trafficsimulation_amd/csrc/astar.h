@@ -233,6 +233,195 @@ __device__ int astar_dev(const Dev& d, const TsParams& P, AScratch& S, int start
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same search spread over one wavefront.  All 64 lanes call it with identical arguments and get the same
+// return value; the scratch (table, heap, dir bytes, output) is the searcher's, as for astar_dev.  The algorithm is
+// the sequential one - same heap layout, same comparisons, same order of relaxations - only its memory traffic
+// is organised by lanes so that a step costs one round trip instead of one per access:
+//   * sift-down: the 62 entries of the next five levels below the hole are fetched at once (one per lane) and the
+//     walk down those levels reads them with cross-lane shuffles;
+//   * sift-up of a push: the (at most 31) ancestors of the new slot are fetched at once, a ballot finds how far
+//     the entry rises, the lanes holding ancestors write them one level down in parallel;
+//   * the four neighbours are prepared on lanes 0-3 (cell record, density, table probe), then committed in the
+//     reference's order N, E, S, W.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_wave_barrier(); }
+
+__device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int start_idx, int goal_idx, bool soft,
+                          bool ignore_flow, int maximum_steps, int32_t* out, int out_cap) {
+  const int W = d.W, H = d.H;
+  const int lane = lane_id();
+  S.calls++;
+  S.epoch++;
+  if (S.epoch == 0) {
+    for (uint32_t q = lane; q <= S.hmask; q += 64) S.ht[q].stamp = 0;
+    S.epoch = 1;
+    wave_mem_sync();
+  }
+  S.nodes = 0;
+  const int gx = goal_idx % W, gy = goal_idx / W;
+  {
+    bool f; HEnt e;
+    uint32_t h = h_probe(S, start_idx, f, e);
+    if (lane == 0) S.ht[h] = HEnt{start_idx, 0, -1, S.epoch};
+    S.nodes = 1;
+    if (S.nodes > S.peak_nodes) S.peak_nodes = S.nodes;
+  }
+  int heap_size = 1;
+  {
+    int sx = start_idx % W, sy = start_idx / W;
+    if (lane == 0) { S.hq[0] = QEnt{abs(sx - gx) + abs(sy - gy), 0, 0, start_idx}; S.hd[0] = -1; }
+  }
+  wave_mem_sync();
+  // relative position of this lane inside a 63-entry window hanging below a hole: level and offset in the level
+  const int rel = lane;                                  // 0 = the hole itself (unused), 1..62 = five levels below it
+  const int rlvl = 31 - __builtin_clz((unsigned)(rel + 1));   // 0 for rel 0, 1 for 1-2, ... 5 for 31-62
+  const int roff = (rel + 1) - (1 << rlvl);
+  while (heap_size > 0) {
+    const QEnt top = S.hq[0];
+    const int g = top.g, steps = top.s, cur = top.i;
+    const int prev_dir = S.hd[0];
+    heap_size--;
+    if (heap_size > 0) {
+      const QEnt x = S.hq[heap_size];
+      const int8_t xd = S.hd[heap_size];
+      wave_mem_sync();                     // every lane has read hd[0] / hq[0] before they are overwritten
+      if (lane == 0) S.hd[0] = xd;
+      long long idx = 0;                   // the hole; x keeps sinking
+      bool placed = false;
+      while (!placed) {
+        // fetch the window below the hole
+        const long long abs_l = ((idx + 1) << rlvl) + roff - 1;
+        const bool in_heap = lane >= 1 && lane <= 62 && abs_l < heap_size;
+        QEnt mine = in_heap ? S.hq[abs_l] : QEnt{0x7FFFFFFF, 0, 0, 0};
+        int cur_rel = 0;
+        long long cur_abs = idx;
+#pragma unroll
+        for (int lv = 0; lv < 5; lv++) {
+          const int l_rel = 2 * cur_rel + 1, r_rel = l_rel + 1;
+          const long long l_abs = 2 * cur_abs + 1, r_abs = l_abs + 1;
+          if (l_abs >= heap_size) { if (lane == 0) S.hq[cur_abs] = x; placed = true; break; }
+          const int lf = __shfl(mine.f, l_rel), rf = __shfl(mine.f, r_rel);
+          int smallest = cur_rel, fs = x.f;
+          if (lf < fs) { smallest = l_rel; fs = lf; }
+          if (r_abs < heap_size && rf < fs) smallest = r_rel;
+          if (smallest == cur_rel) { if (lane == 0) S.hq[cur_abs] = x; placed = true; break; }
+          if (lane == smallest) S.hq[cur_abs] = mine;     // the child moves up
+          cur_abs = smallest == l_rel ? l_abs : r_abs;
+          cur_rel = smallest;
+        }
+        if (!placed) idx = cur_abs;       // five levels down and still sinking: next window
+      }
+    }
+    wave_mem_sync();
+    if (cur == goal_idx) {
+      int len = 0;
+      for (int idx = cur; idx != start_idx;) {
+        bool f; HEnt e;
+        h_probe(S, idx, f, e);
+        idx = e.came;
+        len++;
+      }
+      if (len > out_cap) return -1;
+      int k = len;
+      for (int idx = cur; idx != start_idx;) {
+        --k;
+        if (lane == 0) out[k] = idx;
+        bool f; HEnt e;
+        h_probe(S, idx, f, e);
+        idx = e.came;
+      }
+      wave_mem_sync();
+      return len;
+    }
+    {
+      bool f; HEnt e;
+      h_probe(S, cur, f, e);
+      if (g > (f ? e.dist : A_INF)) continue;
+    }
+    S.expansions++;
+    const int cx = cur % W, cy = cur / W;
+    const uint8_t bits = (uint8_t)st_allowed(d.cell[cur].stat);
+    // ---- prepare: lane dd < 4 evaluates neighbour dd -------------------------------------------------------
+    const int dd_l = lane & 3;
+    const int nx_l = cx + (dd_l == 1) - (dd_l == 3), ny_l = cy + (dd_l == 0) - (dd_l == 2);
+    bool ok_l = lane < 4 && nx_l >= 0 && nx_l < W && ny_l >= 0 && ny_l < H && steps + 1 <= maximum_steps;
+    const int nidx_l = ok_l ? ny_l * W + nx_l : cur;
+    double ng_l = g + 1;
+    bool found_l = false;
+    HEnt e_l = HEnt{0, 0, 0, 0};
+    uint32_t h_l = 0;
+    if (ok_l) {
+      const Cell nc = d.cell[nidx_l];
+      if (P.turn_penalty_enabled && prev_dir != -1 && dd_l != prev_dir) ng_l += P.turn_penalty;
+      if ((bits & (1 << dd_l)) == 0) {
+        if (ignore_flow && st_is_road(nc.stat) == 1) ng_l += P.contraflow_penalty;
+        else ok_l = false;
+      }
+      if (ok_l && nc.occ == 1) {
+        if (soft && P.dynamic_penalties_enabled) {
+          double p = P.obstacle_penalty_vehicle;
+          double local_density = (double)d.density[nidx_l];
+          ng_l += (double)(long long)(p * (1.0 + P.dynamic_penalty_scale * local_density));
+        } else if (soft) ng_l += P.obstacle_penalty_vehicle;
+        else ok_l = false;
+      }
+      if (ok_l && nc.stop == 1) {
+        if (soft) ng_l += P.obstacle_penalty_stop;
+        else ok_l = false;
+      }
+      if (ok_l && P.road_type_penalties_enabled && st_is_road(nc.stat) == 1) {
+        int rt = st_road_type(nc.stat);
+        if (rt == 1) ng_l += P.road_type_penalty_r1;
+        else if (rt == 2) ng_l += P.road_type_penalty_r2;
+        else if (rt == 3) ng_l += P.road_type_penalty_r3;
+      }
+      if (ok_l) h_l = h_probe(S, nidx_l, found_l, e_l);
+    }
+    // ---- commit in the reference's order --------------------------------------------------------------------
+    bool table_grew = false;
+    for (int dd = 0; dd < 4; dd++) {
+      if (!__shfl((int)ok_l, dd)) continue;
+      const int nidx = __shfl(nidx_l, dd);
+      const double ng = __shfl(ng_l, dd);
+      bool found = __shfl((int)found_l, dd) != 0;
+      uint32_t h = (uint32_t)__shfl((int)h_l, dd);
+      int dist_n = __shfl(e_l.dist, dd);
+      if (table_grew) {   // a key went in since the probe: it may sit where this one would have gone
+        HEnt e;
+        h = h_probe(S, nidx, found, e);
+        dist_n = e.dist;
+      }
+      if (!(ng < (double)(found ? dist_n : A_INF))) continue;
+      S.relaxations++;
+      if (!found) {
+        if (S.nodes >= S.node_cap) return -1;
+        S.nodes++;
+        if (S.nodes > S.peak_nodes) S.peak_nodes = S.nodes;
+        table_grew = true;
+      }
+      if (heap_size >= S.heap_cap) return -1;
+      const int nx = nidx % W, ny = nidx / W;
+      const QEnt x{(int)(ng + (double)(abs(nx - gx) + abs(ny - gy))), (int)ng, steps + 1, nidx};
+      const long long i = heap_size;
+      // ancestors of slot i: a_k = ((i + 1) >> k) - 1, k = 1 .. depth; lane k - 1 fetches a_k
+      const int depth = 63 - __builtin_clzll((unsigned long long)(i + 1));
+      const long long a_mine = ((i + 1) >> (lane + 1)) - 1;
+      const bool has = lane < depth;
+      const QEnt anc = has ? S.hq[a_mine] : QEnt{(int)0x80000000, 0, 0, 0};
+      const unsigned long long rises = __ballot(has && x.f < anc.f);
+      const int r = rises == ~0ull ? 64 : __builtin_ctzll(~rises);      // leading ancestors the entry passes
+      if (lane == 0) { S.ht[h] = HEnt{nidx, (int)ng, cur, S.epoch}; S.hd[i] = (int8_t)dd; }
+      if (lane < r) S.hq[((i + 1) >> lane) - 1] = anc;                 // ancestor k moves to where k - 1 was
+      if (lane == 0) S.hq[((i + 1) >> r) - 1] = x;
+      heap_size++;
+      wave_mem_sync();
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // vehicle working state for one step_decide
 // ---------------------------------------------------------------------------------------------
 struct VW {
@@ -722,12 +911,13 @@ __global__ void __launch_bounds__(64) k_decide_replan_lds(Dev d, TsParams P, ATi
 }
 
 // one search on the current maps (the `astar(...)` operator seam, ts_astar) - slot 0 of tier `t`
-__global__ void k_astar_single(Dev d, TsParams P, ATier t, int start_idx, int goal_idx, int soft, int ignore_flow,
-                               int maximum_steps, int32_t* out_len) {
-  if (threadIdx.x || blockIdx.x) return;
+__global__ void __launch_bounds__(64) k_astar_single(Dev d, TsParams P, ATier t, int start_idx, int goal_idx, int soft,
+                                                      int ignore_flow, int maximum_steps, int32_t* out_len) {
+  if (blockIdx.x) return;
   AScratch S;
   scratch_bind(t, 0, S);
-  int len = astar_dev(d, P, S, start_idx, goal_idx, soft != 0, ignore_flow != 0, maximum_steps, S.A, S.cap);
+  int len = astar_wave(d, P, S, start_idx, goal_idx, soft != 0, ignore_flow != 0, maximum_steps, S.A, S.cap);
+  if (threadIdx.x) return;
   t.slot_epoch[0] = S.epoch;
   if (len >= 0) {
     atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);

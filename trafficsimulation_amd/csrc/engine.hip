@@ -2908,6 +2908,13 @@ static int add_vehicle_planned(ts_handle e, int start, int goal, int pop_type) {
   return plan_vehicle(e, e->n_vehicles_total - 1, start, goal);
 }
 
+// A search that runs alone gains nothing from a small scratch tier (tiers only buy concurrency), and one that outgrows
+// its tier is run again from scratch: start where a search between these two cells very likely fits.
+static int first_tier_for(ts_handle e, int start, int goal) {
+  const int md = std::abs(start % e->W - goal % e->W) + std::abs(start / e->W - goal / e->W);
+  return md < 48 ? 0 : md < 400 ? 1 : md < 2500 ? 2 : 3;
+}
+
 // self.path = self._compute_path() for a vehicle standing on `start` with target `goal` (both already on the
 // device): city._path_cache first, then the phase 0-4 planner on the maps as they are now
 static int plan_vehicle(ts_handle e, int vid, int start, int goal) {
@@ -2931,7 +2938,7 @@ static int plan_vehicle(ts_handle e, int vid, int start, int goal) {
     }
   }
   if (!e->density_valid) { rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
-  for (int t = 0; t < ts_engine::N_TIERS; t++) {
+  for (int t = first_tier_for(e, start, goal); t < ts_engine::N_TIERS; t++) {
     rc = ensure_tier(e, t);
     if (rc) return rc;
     for (int attempt = 0; attempt < 3; attempt++) {
@@ -3235,7 +3242,7 @@ int ts_astar(ts_handle e, int32_t sx, int32_t sy, int32_t gx, int32_t gy, int32_
   int rc = ensure_density(e, e->d.occ);  // "evaluated on the engine's current maps"
   if (rc) return rc;
   e->density_valid = false;
-  for (int t = 0; t < ts_engine::N_TIERS; t++) {
+  for (int t = first_tier_for(e, sy * e->W + sx, gy * e->W + gx); t < ts_engine::N_TIERS; t++) {
     rc = ensure_tier(e, t);
     if (rc) return rc;
     hipLaunchKernelGGL(k_astar_single, dim3(1), dim3(64), 0, e->stream, e->d, e->P, e->tier[t], sy * e->W + sx,
