@@ -1,4 +1,4 @@
-// astar.h - GPU A* (one search per lane) and the replanning policy of VehicleAgent.
+// astar.h - GPU A* (one search per wave) and the replanning policy of VehicleAgent.
 //
 // astar_dev restates astar_numba.py:87-239 verbatim, quirks included:
 //   * binary heap keyed on f only, strict '<' in both sift routines (52-85);
@@ -856,12 +856,14 @@ __global__ void k_decide_main(Dev d, TsParams P, int n_active, RLists lists) {
   }
 }
 
-// replanning vehicles: one lane per vehicle, private scratch from tier `t`.  Entries that outgrow the tier go
+// replanning vehicles: one wave per vehicle, private scratch from tier `t`.  Entries that outgrow the tier go
 // to `next_list` (counter replan_n[next_counter]); entries that find the pool full go to `retry_list`.
-__global__ void k_decide_replan(Dev d, TsParams P, ATier t, const int32_t* list, int begin, int n, int32_t* next_list,
+__global__ void __launch_bounds__(64) k_decide_replan(Dev d, TsParams P, ATier t, const int32_t* list, int begin, int n, int32_t* next_list,
                                 int next_counter, int32_t* retry_list, int stage, StageCaps caps) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+  // one wave per vehicle, lane 0 works: 64 independent searches in one wave run in lockstep and pay for each
+  // other's branches, and a tick rarely offers enough long searches to need the lanes
+  const int j = blockIdx.x;
+  if (j >= n || threadIdx.x != 0) return;
   AScratch S;
   scratch_bind(t, j, S);
   const int i = list[begin + j];

@@ -1473,7 +1473,7 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
           LAUNCH(e, PK_REPLAN, cnt, k_decide_replan_lds, dim3(cnt), dim3(64), d, P, T, e->replan_list[sg.in_list], begin, cnt,
                  e->replan_list[sg.out_list], sg.out_counter, e->replan_list[3], caps);
         else
-          LAUNCH(e, PK_REPLAN, cnt, k_decide_replan, dim3(nblk(cnt, 64)), dim3(64), d, P, T, e->replan_list[sg.in_list], begin,
+          LAUNCH(e, PK_REPLAN, cnt, k_decide_replan, dim3(cnt), dim3(64), d, P, T, e->replan_list[sg.in_list], begin,
                  cnt, e->replan_list[sg.out_list], sg.out_counter, e->replan_list[3], sidx, caps);
       }
       const double tl = now_ms();
