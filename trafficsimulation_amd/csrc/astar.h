@@ -851,7 +851,13 @@ __global__ void k_decide_main(Dev d, TsParams P, int n_active, RLists lists) {
   if (i >= n_active) return;
   if (d.cnt->rng_event != 0xFFFFFFFFu) return;  // a malfunction / sideswipe fired: the host re-runs this after the fix-up
   if (decide_vehicle(d, P, i, nullptr) == DV_DEFER) {
-    const int h = min((int)d.tier_hint[d.active[i]], 4);   // start where its last search fitted
+    // start where its last search fitted, or where a search over this distance is likely to fit: the searches are
+    // Dijkstra-like (the heuristic is far below the penalties), so they touch on the order of md^2 / 2 cells
+    const int vid = d.active[i];
+    const int p0 = d.pos[vid], p1 = d.target[vid];
+    const int md = abs(p0 % d.W - p1 % d.W) + abs(p0 / d.W - p1 / d.W);
+    const int by_dist = md < 40 ? 0 : md < 60 ? 1 : md < 240 ? 2 : md < 680 ? 3 : 4;
+    const int h = min(max((int)d.tier_hint[vid], by_dist), 4);
     lists.l[stage_list(h)][atomicAdd(&d.cnt->replan_n[stage_counter(h)], 1)] = i;
   }
 }

@@ -1349,7 +1349,8 @@ int ensure_tier(E* e, int t) {
                                               std::min<long long>(N, 262144), N};
   const long long last_bytes = N * (2 * 16 + 4 * 17 + 5 * 4);   // table + heap + dir bytes + five cell buffers, per slot
   const int last_slots = (int)std::max<long long>(4, std::min<long long>(64, (16ll << 30) / std::max<long long>(last_bytes, 1)));
-  const int slots[ts_engine::N_TIERS] = {16384, 1024, 128, last_slots};
+  // slots by a ~16 GB budget per tier (allocated on first use; small maps cap the per-slot size at N)
+  const int slots[ts_engine::N_TIERS] = {16384, 4096, 512, last_slots};
   T.cap = (int)caps[t];
   T.n_slots = slots[t];
   uint32_t hs = 1;
