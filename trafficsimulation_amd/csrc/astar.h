@@ -523,6 +523,16 @@ __device__ __forceinline__ void swap_ptr(int32_t*& a, int32_t*& b) { int32_t* t 
 
 // _compute_path_internal (vehicle_base.py:199-420).  On success the result is in S.P[0..*out_len) (possibly
 // empty).  Returns false on tier overflow.
+// WAVE: the caller runs with all 64 lanes of its wave executing the same code on the same values (one vehicle per
+// wave); plain stores are then harmless duplicates, atomics are issued by lane 0 only, and the searches use
+// astar_wave.  !WAVE: one vehicle per lane (k_decide_main), nothing is shared.
+template <bool WAVE>
+__device__ __forceinline__ int astar_any(const Dev& d, const TsParams& P, AScratch& S, int start_idx, int goal_idx, bool soft,
+                                         bool ignore_flow, int maximum_steps, int32_t* out, int out_cap) {
+  if (WAVE) return astar_wave(d, P, S, start_idx, goal_idx, soft, ignore_flow, maximum_steps, out, out_cap);
+  return astar_dev(d, P, S, start_idx, goal_idx, soft, ignore_flow, maximum_steps, out, out_cap);
+}
+template <bool WAVE>
 __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScratch& S, VW& v, int& out_len) {
   // ---- phase 0: re-merge with the saved original path (219-277) ----
   for (int which = 0; which < 2; which++) {
@@ -537,7 +547,7 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
       if (d.cell[c].occ == 0) { merge_idx = q; b = c; break; }
     }
     if (merge_idx < 0) continue;
-    int bl = astar_dev(d, P, S, v.pos, b, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
+    int bl = astar_any<WAVE>(d, P, S, v.pos, b, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
     if (bl < 0) return false;
     if (bl > 0 && S.BYP[bl - 1] == b) {
       int n = 0;
@@ -562,11 +572,11 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
     S.calls++;
     la = 0;
   } else {
-    la = astar_dev(d, P, S, v.pos, sx_goal, false, false, 0x7FFFFFFF, S.A, S.cap);
+    la = astar_any<WAVE>(d, P, S, v.pos, sx_goal, false, false, 0x7FFFFFFF, S.A, S.cap);
     if (la < 0) return false;
   }
   if (la == 0) {
-    la = astar_dev(d, P, S, v.pos, sx_goal, true, false, 0x7FFFFFFF, S.A, S.cap);
+    la = astar_any<WAVE>(d, P, S, v.pos, sx_goal, true, false, 0x7FFFFFFF, S.A, S.cap);
     if (la < 0) return false;
   }
   // ---- phase 3: contraflow overtake of a stranded / parked blocker (309-366) ----
@@ -584,7 +594,7 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
         int bt = -1, idx_bp = -1;
         for (int q = 0; q < la; q++) if (d.cell[S.A[q]].occ == 0) { bt = S.A[q]; idx_bp = q; break; }
         if (bt >= 0) {
-          int bl = astar_dev(d, P, S, v.pos, bt, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
+          int bl = astar_any<WAVE>(d, P, S, v.pos, bt, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
           if (bl < 0) return false;
           if (bl > 1 && S.BYP[bl - 1] == bt) {
             // idx_bp = first index of bt in path = the index found above (first free cell)
@@ -614,7 +624,7 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
       int bt = -1, merge_idx = -1;
       for (int q = 0; q < la; q++) if (d.cell[S.A[q]].occ == 0) { bt = S.A[q]; merge_idx = q; break; }
       if (bt >= 0) {
-        int bl = astar_dev(d, P, S, v.pos, bt, true, true, P.max_contraflow_stuck_detour_steps, S.BYP, MAXB);
+        int bl = astar_any<WAVE>(d, P, S, v.pos, bt, true, true, P.max_contraflow_stuck_detour_steps, S.BYP, MAXB);
         if (bl < 0) return false;
         if (bl > 1 && S.BYP[bl - 1] == bt) {
           int n = 0;
@@ -656,8 +666,11 @@ __device__ bool ax_contains(const Dev& d, const AScratch* S, const VW& v, int k,
 }
 
 // device-side bump allocation in the path pool; returns false when the pool is exhausted
+template <bool WAVE>
 __device__ __forceinline__ bool pool_alloc(const Dev& d, int words, uint32_t& off) {
-  unsigned long long o = atomicAdd((unsigned long long*)&d.cnt->pool_used, (unsigned long long)words);
+  unsigned long long o = 0;
+  if (!WAVE || lane_id() == 0) o = atomicAdd((unsigned long long*)&d.cnt->pool_used, (unsigned long long)words);
+  if (WAVE) o = ((unsigned long long)(unsigned)__shfl((int)(o >> 32), 0) << 32) | (unsigned)__shfl((int)(unsigned)o, 0);
   if (o + (unsigned long long)words > (unsigned long long)d.pool_cap_words) return false;
   off = (uint32_t)o;
   return true;
@@ -678,7 +691,9 @@ __device__ void encode_cells(const Dev& d, uint32_t off, int start_cell, const i
 
 // step_decide for vehicle number i of active_vehicle_agents.  S == nullptr: run until a search is needed
 // (returns DV_DEFER without side effects).  Otherwise completes, unless the tier overflows or the pool is full.
+template <bool WAVE>
 __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* S) {
+  const bool one = !WAVE || lane_id() == 0;   // the lane that issues this vehicle's atomics
   const int vid = d.active[i];
   if (vid < 0) return DV_DONE;
   VW v;
@@ -734,7 +749,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
       if (!S) return DV_DEFER;
       v.cooldown = P.pathfinding_cooldown;
       int len;
-      if (!compute_path_internal_dev(d, P, *S, v, len)) return DV_OVERFLOW;
+      if (!compute_path_internal_dev<WAVE>(d, P, *S, v, len)) return DV_OVERFLOW;
       v.newpath = true; v.plen = len; path_changed = true;
     }
     // _recompute_path_on_obstacle (454-504)
@@ -771,7 +786,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
       v.cooldown = P.pathfinding_cooldown;
       const bool keep_new = v.newpath;
       int len;
-      if (!compute_path_internal_dev(d, P, *S, v, len)) return DV_OVERFLOW;
+      if (!compute_path_internal_dev<WAVE>(d, P, *S, v, len)) return DV_OVERFLOW;
       if (len > 0) {
         v.newpath = true; v.plen = len; path_changed = true;
         scan_ahead_dev(d, P, S, v, idx_stop, idx_veh, first_cell);
@@ -799,7 +814,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
     int words = path_changed ? (v.plen + 15) / 16 : 0;
     for (int k = 0; k < 4; k++) if (v.ax_staged[k]) words += (v.ax_len[k] + 15) / 16;
     uint32_t off = 0;
-    if (words > 0 && !pool_alloc(d, words, off)) return DV_POOL_FULL;
+    if (words > 0 && !pool_alloc<WAVE>(d, words, off)) return DV_POOL_FULL;
     if (path_changed) {
       encode_cells(d, off, v.pos, S->P, v.plen);
       d.path_off[vid] = off; d.path_len[vid] = v.plen; d.path_cur[vid] = 0;
@@ -816,17 +831,17 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
     if (ax_none_set[0] && !v.ax_staged[0]) d.ax_len[0][vid] = -1;
     if (ax_none_set[1] && !v.ax_staged[2]) d.ax_len[2][vid] = -1;
     d.cooldown[vid] = v.cooldown; d.over_dur[vid] = v.over_dur; d.det_dur[vid] = v.det_dur;
-    if (v.d_overtaking) atomicAdd((unsigned long long*)&d.cnt->overtaking, (unsigned long long)v.d_overtaking);
-    if (v.d_detour) atomicAdd((unsigned long long*)&d.cnt->in_stuck_detour, (unsigned long long)v.d_detour);
+    if (one && v.d_overtaking) atomicAdd((unsigned long long*)&d.cnt->overtaking, (unsigned long long)v.d_overtaking);
+    if (one && v.d_detour) atomicAdd((unsigned long long*)&d.cnt->in_stuck_detour, (unsigned long long)v.d_detour);
   }
   if (write_stranded) d.stranded_left[vid] = stranded_left;
-  if (dc_coll) atomicAdd((unsigned long long*)&d.cnt->collisions, (unsigned long long)(long long)dc_coll);
-  if (dc_malf) atomicAdd((unsigned long long*)&d.cnt->malfunctions, (unsigned long long)(long long)dc_malf);
+  if (one && dc_coll) atomicAdd((unsigned long long*)&d.cnt->collisions, (unsigned long long)(long long)dc_coll);
+  if (one && dc_malf) atomicAdd((unsigned long long*)&d.cnt->malfunctions, (unsigned long long)(long long)dc_malf);
   d.max_steps[vid] = (int8_t)max_steps;
   d.base_speed[vid] = (int8_t)v.base;
   d.cur_speed[vid] = (int8_t)v.cur;
   d.flags[vid] = early ? (v.f | VF_EARLY) : v.f;
-  if (arrived) {
+  if (arrived && one) {
     if (!(v.f & VF_KEEP)) atomicExch(&d.cnt->error, TS_E_UNSUPPORTED);  // despawn inside decide (start == goal)
     else if (v.f & VF_TOBLOCK) svc_record(d, i, vid, AR_DECIDE);        // ServiceVehicleAgent._start_service
     else {   // base on_target_reached of a vehicle that stays: trip statistics once more, then _park()
@@ -850,7 +865,7 @@ __global__ void k_decide_main(Dev d, TsParams P, int n_active, RLists lists) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_active) return;
   if (d.cnt->rng_event != 0xFFFFFFFFu) return;  // a malfunction / sideswipe fired: the host re-runs this after the fix-up
-  if (decide_vehicle(d, P, i, nullptr) == DV_DEFER) {
+  if (decide_vehicle<false>(d, P, i, nullptr) == DV_DEFER) {
     // start where its last search fitted, or where a search over this distance is likely to fit: the searches are
     // Dijkstra-like (the heuristic is far below the penalties), so they touch on the order of md^2 / 2 cells
     const int vid = d.active[i];
@@ -866,14 +881,15 @@ __global__ void k_decide_main(Dev d, TsParams P, int n_active, RLists lists) {
 // to `next_list` (counter replan_n[next_counter]); entries that find the pool full go to `retry_list`.
 __global__ void __launch_bounds__(64) k_decide_replan(Dev d, TsParams P, ATier t, const int32_t* list, int begin, int n, int32_t* next_list,
                                 int next_counter, int32_t* retry_list, int stage, StageCaps caps) {
-  // one wave per vehicle, lane 0 works: 64 independent searches in one wave run in lockstep and pay for each
-  // other's branches, and a tick rarely offers enough long searches to need the lanes
+  // one wave per vehicle (64 independent searches in one wave would run in lockstep and pay for each other's
+  // branches); all 64 lanes run the vehicle's step_decide together and share the work inside the searches
   const int j = blockIdx.x;
-  if (j >= n || threadIdx.x != 0) return;
+  if (j >= n) return;
   AScratch S;
   scratch_bind(t, j, S);
   const int i = list[begin + j];
-  int r = decide_vehicle(d, P, i, &S);
+  int r = decide_vehicle<true>(d, P, i, &S);
+  if (threadIdx.x != 0) return;
   t.slot_epoch[j] = S.epoch;
   if (r == DV_DONE) {  // work of attempts that are re-run on a larger tier / after pool growth is not counted twice
     note_tier(d, S, d.active[i], stage, caps);
@@ -899,7 +915,6 @@ __global__ void __launch_bounds__(64) k_decide_replan_lds(Dev d, TsParams P, ATi
   if (j >= n) return;
   for (int q = threadIdx.x; q < LDS_HASH; q += 64) s_ht[q].stamp = 0;
   __syncthreads();
-  if (threadIdx.x != 0) return;
   AScratch S;
   scratch_bind(cells_tier, j, S);   // cell buffers (paths) from the arena of the first HBM tier
   S.ht = s_ht; S.hmask = LDS_HASH - 1; S.hq = s_hq; S.hd = s_hd; S.heap_cap = LDS_HEAP;
@@ -907,7 +922,8 @@ __global__ void __launch_bounds__(64) k_decide_replan_lds(Dev d, TsParams P, ATi
   S.peak_nodes = 0;
   S.epoch = 0;
   const int i = list[begin + j];
-  int r = decide_vehicle(d, P, i, &S);
+  int r = decide_vehicle<true>(d, P, i, &S);
+  if (threadIdx.x != 0) return;
   if (r == DV_DONE) {
     note_tier(d, S, d.active[i], 0, caps);
     atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
@@ -937,8 +953,9 @@ __global__ void __launch_bounds__(64) k_astar_single(Dev d, TsParams P, ATier t,
 
 // VehicleAgent.__init__ -> self.path = self._compute_path() on a cache miss (vehicle_base.py:80-81, 143-167):
 // the phase 0-4 planner for a freshly placed vehicle.  status: path length, or -1 overflow / -2 pool full.
-__global__ void k_spawn_plan(Dev d, TsParams P, ATier t, int vid, int32_t* status) {
-  if (threadIdx.x || blockIdx.x) return;
+__global__ void __launch_bounds__(64) k_spawn_plan(Dev d, TsParams P, ATier t, int vid, int32_t* status) {
+  if (blockIdx.x) return;
+  const bool one = threadIdx.x == 0;
   AScratch S;
   scratch_bind(t, 0, S);
   VW v;
@@ -949,16 +966,18 @@ __global__ void k_spawn_plan(Dev d, TsParams P, ATier t, int vid, int32_t* statu
   v.reach_known = false;
   for (int k = 0; k < 4; k++) { v.ax_staged[k] = false; v.ax_len[k] = d.ax_len[k][vid]; }
   int len;
-  bool ok = compute_path_internal_dev(d, P, S, v, len);
+  bool ok = compute_path_internal_dev<true>(d, P, S, v, len);
   t.slot_epoch[0] = S.epoch;
   if (!ok) { *status = -1; return; }
   int words = (len + 15) / 16;
   for (int k = 0; k < 4; k++) if (v.ax_staged[k]) words += (v.ax_len[k] + 15) / 16;
   uint32_t off = 0;
-  if (words > 0 && !pool_alloc(d, words, off)) { *status = -2; return; }
-  atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
-  atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
-  atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
+  if (words > 0 && !pool_alloc<true>(d, words, off)) { *status = -2; return; }
+  if (one) {
+    atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
+    atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
+    atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
+  }
   encode_cells(d, off, v.pos, S.P, len);
   d.path_off[vid] = off; d.path_len[vid] = len; d.path_cur[vid] = 0;
   off += (len + 15) / 16;
@@ -969,8 +988,8 @@ __global__ void k_spawn_plan(Dev d, TsParams P, ATier t, int vid, int32_t* statu
     off += (v.ax_len[k] + 15) / 16;
   }
   d.flags[vid] = v.f; d.over_dur[vid] = v.over_dur; d.det_dur[vid] = v.det_dur;
-  if (v.d_overtaking) atomicAdd((unsigned long long*)&d.cnt->overtaking, (unsigned long long)v.d_overtaking);
-  if (v.d_detour) atomicAdd((unsigned long long*)&d.cnt->in_stuck_detour, (unsigned long long)v.d_detour);
+  if (one && v.d_overtaking) atomicAdd((unsigned long long*)&d.cnt->overtaking, (unsigned long long)v.d_overtaking);
+  if (one && v.d_detour) atomicAdd((unsigned long long*)&d.cnt->in_stuck_detour, (unsigned long long)v.d_detour);
   *status = len;
 }
 
