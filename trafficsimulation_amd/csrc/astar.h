@@ -259,7 +259,8 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
     wave_mem_sync();
   }
   S.nodes = 0;
-  const int gx = goal_idx % W, gy = goal_idx / W;
+  int gx, gy;
+  cell_xy(d, goal_idx, gx, gy);
   {
     bool f; HEnt e;
     uint32_t h = h_probe(S, start_idx, f, e);
@@ -269,7 +270,8 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   }
   int heap_size = 1;
   {
-    int sx = start_idx % W, sy = start_idx / W;
+    int sx, sy;
+    cell_xy(d, start_idx, sx, sy);
     if (lane == 0) { S.hq[0] = QEnt{abs(sx - gx) + abs(sy - gy), 0, 0, start_idx}; S.hd[0] = -1; }
   }
   wave_mem_sync();
@@ -340,7 +342,8 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
       if (g > (f ? e.dist : A_INF)) continue;
     }
     S.expansions++;
-    const int cx = cur % W, cy = cur / W;
+    int cx, cy;
+    cell_xy(d, cur, cx, cy);
     const uint8_t bits = (uint8_t)st_allowed(d.cell[cur].stat);
     // ---- prepare: lane dd < 4 evaluates neighbour dd -------------------------------------------------------
     const int dd_l = lane & 3;
@@ -401,7 +404,7 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
         table_grew = true;
       }
       if (heap_size >= S.heap_cap) return -1;
-      const int nx = nidx % W, ny = nidx / W;
+      const int nx = __shfl(nx_l, dd), ny = __shfl(ny_l, dd);
       const QEnt x{(int)(ng + (double)(abs(nx - gx) + abs(ny - gy))), (int)ng, steps + 1, nidx};
       const long long i = heap_size;
       // ancestors of slot i: a_k = ((i + 1) >> k) - 1, k = 1 .. depth; lane k - 1 fetches a_k

@@ -63,6 +63,7 @@ __host__ __device__ __forceinline__ int st_road_type(uint8_t s) { return (s >> 6
 
 struct Dev {
   int W, H, N;
+  unsigned long long w_magic;   // floor(2^40 / W) + 1: y = (cell * w_magic) >> 40 is exact for cell < 2^26, W < 2^14
   double elapsed;   // DynamicTrafficAgent.elapsed as the decide phase sees it (before the clock agent steps)
   Cell* cell;
   // dense byte planes kept next to the records: occ and stop are written through (light groups sum lanes of
@@ -130,6 +131,11 @@ __device__ __forceinline__ int step_cell(int cell, int dir, int W) {
 }
 __device__ __forceinline__ void set_occ(const Dev& d, int c, int8_t v) { d.cell[c].occ = v; d.occ[c] = v; }
 __device__ __forceinline__ void set_stop(const Dev& d, int c, int8_t v) { d.cell[c].stop = v; d.stop[c] = v; }
+// cell -> (x, y) without an integer division (falls back to one when the map is beyond the magic number's range)
+__device__ __forceinline__ void cell_xy(const Dev& d, int cell, int& x, int& y) {
+  if (d.w_magic) { y = (int)(((unsigned long long)(unsigned)cell * d.w_magic) >> 40); x = cell - y * d.W; }
+  else { y = cell / d.W; x = cell - y * d.W; }
+}
 __device__ __forceinline__ uint32_t claim_rank(uint32_t v, uint32_t prefix) {
   return (v >> RANK_BITS) == prefix ? (v & RANK_MASK) : NO_RANK;
 }

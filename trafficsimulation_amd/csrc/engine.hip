@@ -2505,6 +2505,7 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   e->W = w->width; e->H = w->height; e->N = w->width * w->height;
   Dev& d = e->d;
   d.W = e->W; d.H = e->H; d.N = e->N;
+  d.w_magic = (!getenv("TS_NO_MAGIC") && e->W < (1 << 14) && (long long)e->N <= (1ll << 26)) ? ((1ull << 40) / (unsigned long long)e->W + 1ull) : 0ull;
   size_t N = e->N;
   auto bail = [&](int code) { ts_destroy(e); return code; };
   if (hipStreamCreate(&e->stream) != hipSuccess) return bail(TS_E_DEVICE);
