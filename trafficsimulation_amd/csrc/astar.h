@@ -246,6 +246,15 @@ __device__ int astar_dev(const Dev& d, const TsParams& P, AScratch& S, int start
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_wave_barrier(); }
+// values every lane holds alike: tell the compiler (scalar registers, scalar branches) / read one lane's copy
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ double rl(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int start_idx, int goal_idx, bool soft,
                           bool ignore_flow, int maximum_steps, int32_t* out, int out_cap) {
@@ -281,12 +290,13 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   const int roff = (rel + 1) - (1 << rlvl);
   while (heap_size > 0) {
     const QEnt top = S.hq[0];
-    const int g = top.g, steps = top.s, cur = top.i;
-    const int prev_dir = S.hd[0];
+    const int g = uni(top.g), steps = uni(top.s), cur = uni(top.i);
+    const int prev_dir = uni((int)S.hd[0]);
     heap_size--;
     if (heap_size > 0) {
-      const QEnt x = S.hq[heap_size];
-      const int8_t xd = S.hd[heap_size];
+      QEnt x = S.hq[heap_size];
+      x.f = uni(x.f); x.g = uni(x.g); x.s = uni(x.s); x.i = uni(x.i);
+      const int8_t xd = (int8_t)uni((int)S.hd[heap_size]);
       wave_mem_sync();                     // every lane has read hd[0] / hq[0] before they are overwritten
       if (lane == 0) S.hd[0] = xd;
       long long idx = 0;                   // the hole; x keeps sinking
@@ -303,7 +313,7 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
           const int l_rel = 2 * cur_rel + 1, r_rel = l_rel + 1;
           const long long l_abs = 2 * cur_abs + 1, r_abs = l_abs + 1;
           if (l_abs >= heap_size) { if (lane == 0) S.hq[cur_abs] = x; placed = true; break; }
-          const int lf = __shfl(mine.f, l_rel), rf = __shfl(mine.f, r_rel);
+          const int lf = rl(mine.f, l_rel), rf = rl(mine.f, r_rel);
           int smallest = cur_rel, fs = x.f;
           if (lf < fs) { smallest = l_rel; fs = lf; }
           if (r_abs < heap_size && rf < fs) smallest = r_rel;
@@ -339,7 +349,7 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
     {
       bool f; HEnt e;
       h_probe(S, cur, f, e);
-      if (g > (f ? e.dist : A_INF)) continue;
+      if (uni((int)(g > (f ? e.dist : A_INF)))) continue;
     }
     S.expansions++;
     int cx, cy;
@@ -383,17 +393,19 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
     }
     // ---- commit in the reference's order --------------------------------------------------------------------
     bool table_grew = false;
+#pragma unroll
     for (int dd = 0; dd < 4; dd++) {
-      if (!__shfl((int)ok_l, dd)) continue;
-      const int nidx = __shfl(nidx_l, dd);
-      const double ng = __shfl(ng_l, dd);
-      bool found = __shfl((int)found_l, dd) != 0;
-      uint32_t h = (uint32_t)__shfl((int)h_l, dd);
-      int dist_n = __shfl(e_l.dist, dd);
+      if (!rl((int)ok_l, dd)) continue;
+      const int nidx = rl(nidx_l, dd);
+      const double ng = rl(ng_l, dd);
+      bool found = rl((int)found_l, dd) != 0;
+      uint32_t h = (uint32_t)rl((int)h_l, dd);
+      int dist_n = rl(e_l.dist, dd);
       if (table_grew) {   // a key went in since the probe: it may sit where this one would have gone
         HEnt e;
-        h = h_probe(S, nidx, found, e);
-        dist_n = e.dist;
+        h = (uint32_t)uni((int)h_probe(S, nidx, found, e));
+        found = uni((int)found) != 0;
+        dist_n = uni(e.dist);
       }
       if (!(ng < (double)(found ? dist_n : A_INF))) continue;
       S.relaxations++;
@@ -404,7 +416,7 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
         table_grew = true;
       }
       if (heap_size >= S.heap_cap) return -1;
-      const int nx = __shfl(nx_l, dd), ny = __shfl(ny_l, dd);
+      const int nx = rl(nx_l, dd), ny = rl(ny_l, dd);
       const QEnt x{(int)(ng + (double)(abs(nx - gx) + abs(ny - gy))), (int)ng, steps + 1, nidx};
       const long long i = heap_size;
       // ancestors of slot i: a_k = ((i + 1) >> k) - 1, k = 1 .. depth; lane k - 1 fetches a_k
