@@ -293,6 +293,20 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
     const int g = uni(top.g), steps = uni(top.s), cur = uni(top.i);
     const int prev_dir = uni((int)S.hd[0]);
     heap_size--;
+    // Everything the expansion of `cur` will read besides the heap is requested now, so that it travels while the
+    // sift-down below works on the heap (which it does not touch): the cell record of `cur`, and on lanes 0-3 the
+    // record, density and first table probe of neighbour `lane`; on every lane the first probe of `cur` itself.
+    int cx, cy;
+    cell_xy(d, cur, cx, cy);
+    const int dd_l = lane & 3;
+    const int nx_l = cx + (dd_l == 1) - (dd_l == 3), ny_l = cy + (dd_l == 0) - (dd_l == 2);
+    const bool inb_l = lane < 4 && nx_l >= 0 && nx_l < W && ny_l >= 0 && ny_l < H;
+    const int nidx_l = inb_l ? ny_l * W + nx_l : cur;
+    const uint32_t cur_dw = *reinterpret_cast<const uint32_t*>(&d.cell[cur].occ);
+    const uint32_t dyn_l = *reinterpret_cast<const uint32_t*>(&d.cell[nidx_l].occ);
+    const float dens_l = soft && P.dynamic_penalties_enabled ? d.density[nidx_l] : 0.f;
+    const uint32_t slot_l = h_hash(nidx_l, S.hmask), slot_c = h_hash(cur, S.hmask);
+    const HEnt first_l = S.ht[slot_l], first_c = S.ht[slot_c];
     if (heap_size > 0) {
       QEnt x = S.hq[heap_size];
       x.f = uni(x.f); x.g = uni(x.g); x.s = uni(x.s); x.i = uni(x.i);
@@ -347,49 +361,58 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
       return len;
     }
     {
-      bool f; HEnt e;
-      h_probe(S, cur, f, e);
+      bool f; HEnt e = first_c;
+      uint32_t h = slot_c;
+      for (;;) {   // continue the probe of `cur` from the record fetched above
+        if (e.stamp != S.epoch) { f = false; break; }
+        if (e.key == cur) { f = true; break; }
+        h = (h + 1) & S.hmask;
+        e = S.ht[h];
+      }
       if (uni((int)(g > (f ? e.dist : A_INF)))) continue;
     }
     S.expansions++;
-    int cx, cy;
-    cell_xy(d, cur, cx, cy);
-    const uint8_t bits = (uint8_t)st_allowed(d.cell[cur].stat);
-    // ---- prepare: lane dd < 4 evaluates neighbour dd -------------------------------------------------------
-    const int dd_l = lane & 3;
-    const int nx_l = cx + (dd_l == 1) - (dd_l == 3), ny_l = cy + (dd_l == 0) - (dd_l == 2);
-    bool ok_l = lane < 4 && nx_l >= 0 && nx_l < W && ny_l >= 0 && ny_l < H && steps + 1 <= maximum_steps;
-    const int nidx_l = ok_l ? ny_l * W + nx_l : cur;
+    const uint8_t bits = (uint8_t)st_allowed((uint8_t)(cur_dw >> 24));
+    // ---- prepare: lane dd < 4 evaluates neighbour dd from what was fetched before the sift-down ---------------
+    bool ok_l = inb_l && steps + 1 <= maximum_steps;
     double ng_l = g + 1;
     bool found_l = false;
-    HEnt e_l = HEnt{0, 0, 0, 0};
-    uint32_t h_l = 0;
+    HEnt e_l = first_l;
+    uint32_t h_l = slot_l;
     if (ok_l) {
-      const Cell nc = d.cell[nidx_l];
+      const int n_occ = (int8_t)(dyn_l & 0xFF), n_stop = (int8_t)((dyn_l >> 8) & 0xFF);
+      const uint8_t n_stat = (uint8_t)(dyn_l >> 24);
       if (P.turn_penalty_enabled && prev_dir != -1 && dd_l != prev_dir) ng_l += P.turn_penalty;
       if ((bits & (1 << dd_l)) == 0) {
-        if (ignore_flow && st_is_road(nc.stat) == 1) ng_l += P.contraflow_penalty;
+        if (ignore_flow && st_is_road(n_stat) == 1) ng_l += P.contraflow_penalty;
         else ok_l = false;
       }
-      if (ok_l && nc.occ == 1) {
+      if (ok_l && n_occ == 1) {
         if (soft && P.dynamic_penalties_enabled) {
           double p = P.obstacle_penalty_vehicle;
-          double local_density = (double)d.density[nidx_l];
+          double local_density = (double)dens_l;
           ng_l += (double)(long long)(p * (1.0 + P.dynamic_penalty_scale * local_density));
         } else if (soft) ng_l += P.obstacle_penalty_vehicle;
         else ok_l = false;
       }
-      if (ok_l && nc.stop == 1) {
+      if (ok_l && n_stop == 1) {
         if (soft) ng_l += P.obstacle_penalty_stop;
         else ok_l = false;
       }
-      if (ok_l && P.road_type_penalties_enabled && st_is_road(nc.stat) == 1) {
-        int rt = st_road_type(nc.stat);
+      if (ok_l && P.road_type_penalties_enabled && st_is_road(n_stat) == 1) {
+        int rt = st_road_type(n_stat);
         if (rt == 1) ng_l += P.road_type_penalty_r1;
         else if (rt == 2) ng_l += P.road_type_penalty_r2;
         else if (rt == 3) ng_l += P.road_type_penalty_r3;
       }
-      if (ok_l) h_l = h_probe(S, nidx_l, found_l, e_l);
+      if (ok_l) {   // continue the probe from the record fetched above
+        for (;;) {
+          if (e_l.stamp != S.epoch) { found_l = false; break; }
+          if (e_l.key == nidx_l) { found_l = true; break; }
+          h_l = (h_l + 1) & S.hmask;
+          e_l = S.ht[h_l];
+        }
+      }
     }
     // ---- commit in the reference's order --------------------------------------------------------------------
     bool table_grew = false;
