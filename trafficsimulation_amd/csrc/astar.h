@@ -1,6 +1,7 @@
 // astar.h - GPU A* (one search per wave) and the replanning policy of VehicleAgent.
 //
-// astar_dev restates astar_numba.py:87-239 verbatim, quirks included:
+// astar_dev (one lane) and astar_wave (the same search spread over the 64 lanes of a wave; the one the replanning
+// kernels use) restate astar_numba.py:87-239 verbatim, quirks included:
 //   * binary heap keyed on f only, strict '<' in both sift routines (52-85);
 //   * dir_arr lives in heap-SLOT order and is NOT swapped by the sifts, so prev_dir = dir_arr[0] is a
 //     stale slot value (139, 147, 235);
@@ -13,7 +14,8 @@
 // decide_vehicle restates step_decide (vehicle_base.py:616-663) with _recompute_path_on_stuck 506-517,
 // _recompute_path_on_obstacle 454-504, _compute_path 143-167 and _compute_path_internal 199-420
 // (phases 0-4).  It is a pure function of the tick-start state until its final commit, so the same code
-// runs in k_decide_main (no scratch: bails out as soon as a search is needed) and in k_decide_replan.
+// runs in k_decide_main (one vehicle per lane, no scratch: bails out as soon as a search is needed) and in
+// k_decide_replan (one vehicle per wave, every lane executing the same code on the same values).
 #pragma once
 #include "dev.h"
 
