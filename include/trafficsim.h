@@ -341,6 +341,12 @@ int ts_download_groups(ts_handle h, int32_t* rows); /* [G][TS_G_NFIELDS] */
 int ts_num_blocks(ts_handle h);
 int ts_download_blocks(ts_handle h, double* rows);
 int ts_counters(ts_handle h, TsCounters* out);
+/* RainControl card and the /spawn_rain handler (visualization/ui_modules/rain_control.py:22-73):
+ * len(model.rains), RainManager.cooldown / .counter, and RainManager.add_random_rain() called between ticks
+ * (rain.py:100-148: draws from the global stream, appends the cloud to city_model.rains and to the schedule). */
+typedef struct TsRainInfo { int32_t has_manager, n_rains, cooldown, counter; } TsRainInfo;
+int ts_rain_info(ts_handle h, TsRainInfo* out);
+int ts_rain_spawn(ts_handle h);
 
 /* The pathfinder operator seam: astar(width, height, sx, sy, gx, gy, occupancy_map, stop_map,
  * is_road_map, road_type_map, allowed_dirs_map, respect_awareness=False, awareness_range,

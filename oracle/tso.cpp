@@ -1778,6 +1778,23 @@ int tso_download_blocks(ts_handle e, double* rows) {
   for (size_t b = 0; b < e->gen.blocks.size(); b++) { rows[2 * b] = e->gen.blocks[b].food; rows[2 * b + 1] = e->gen.blocks[b].waste; }
   return TS_OK;
 }
+int tso_rain_info(ts_handle e, TsRainInfo* out) {
+  if (!e || !out) return TS_E_INVALID;
+  bool has = false;
+  for (const auto& se : e->sched) if (se.alive && se.kind == TS_AGENT_RAIN_MANAGER) has = true;
+  out->has_manager = has; out->n_rains = (int32_t)e->rains.size();
+  out->cooldown = e->rain_cooldown_left; out->counter = e->rain_counter;
+  return TS_OK;
+}
+int tso_rain_spawn(ts_handle e) {
+  if (!e) return TS_E_INVALID;
+  bool has = false;
+  for (const auto& se : e->sched) if (se.alive && se.kind == TS_AGENT_RAIN_MANAGER) has = true;
+  if (!has) return fail(e, TS_E_STATE, "no RainManager is scheduled");
+  if (!e->seeded[0]) return fail(e, TS_E_STATE, "seed the global stream first");
+  add_random_rain(e);
+  return TS_OK;
+}
 int tso_counters(ts_handle e, TsCounters* out) {
   if (!e || !out) return TS_E_INVALID;
   *out = e->C;

@@ -111,3 +111,19 @@ def run_facade_with_generator(engine, name="service_64_s15", ticks=420):
 
 def test_facade_with_generator_over_oracle(oracle):
     run_facade_with_generator(oracle)
+
+
+def test_facade_rain_control_over_oracle(oracle):
+    """What the RainControl card and the /spawn_rain handler do (rain_control.py:22-73): len(model.rains),
+    rain_manager.cooldown, rain_manager.add_random_rain() between ticks; rain_map then follows the clouds."""
+    tr = load_trace(trace_path("rain_96_s14"))
+    m = CityModel.from_tables(tr, seed=1, defaults=tr["defaults_json"], engine=oracle,
+                              global_state=tr["global_rng_after_worldgen"], sched_state=tr["sched_rng_initial"])
+    assert m.rain_manager.cooldown == 0 and len(m.rains) == 0
+    m.rain_manager.add_random_rain()
+    assert len(m.rains) == 1 and m.rain_manager.counter == 1
+    n_sched = m.schedule.get_agent_count()
+    for _ in range(30):
+        m.step()
+    assert m.rain_map.sum() > 0 or len(m.rains) >= 1
+    assert m.schedule.get_agent_count() >= n_sched - 1   # the cloud is a scheduled agent until it leaves the map

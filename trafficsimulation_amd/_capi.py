@@ -77,6 +77,10 @@ class TsLightTables(C.Structure):
     _fields_ = [("n_groups", C.c_int32), ("n_lights", C.c_int32)] + [(n, C.c_void_p) for n in _LT_PTRS]
 
 
+class TsRainInfo(C.Structure):
+    _fields_ = [("has_manager", C.c_int32), ("n_rains", C.c_int32), ("cooldown", C.c_int32), ("counter", C.c_int32)]
+
+
 class TsCounters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "stuck", "collisions", "malfunctions", "overtaking", "in_stuck_detour", "parked", "live_internal",
@@ -196,7 +200,7 @@ class CApi:
         f("default_params").restype = None
         f("last_error").restype = C.c_char_p
         f("last_error").argtypes = [C.c_void_p]
-        for name in ("destroy", "num_vehicles", "num_groups", "num_scheduled", "num_blocks", "num_spawned"):
+        for name in ("destroy", "num_vehicles", "num_groups", "num_scheduled", "num_blocks", "num_spawned", "rain_spawn"):
             f(name).argtypes = [C.c_void_p]
         f("create").argtypes = [C.POINTER(TsWorld), C.POINTER(TsParams), C.POINTER(C.c_void_p)]
         f("set_lights").argtypes = [C.c_void_p, C.POINTER(TsLightTables)]
@@ -215,6 +219,7 @@ class CApi:
         f("download_path").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         f("download_groups").argtypes = [C.c_void_p, C.c_void_p]
         f("download_blocks").argtypes = [C.c_void_p, C.c_void_p]
+        f("rain_info").argtypes = [C.c_void_p, C.POINTER(TsRainInfo)]
         f("download_vehicle_meta").argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         f("download_service_vehicles").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         f("counters").argtypes = [C.c_void_p, C.POINTER(TsCounters)]
@@ -477,6 +482,15 @@ class CApi:
         blk = np.zeros(cap, dtype=np.int32)
         n = self._chk(self._f("download_service_vehicles")(self.h, idx.ctypes.data, loads.ctypes.data, blk.ctypes.data, cap))
         return idx[:n], loads[:n], blk[:n]
+
+    def rain_info(self) -> TsRainInfo:
+        r = TsRainInfo()
+        self._chk(self._f("rain_info")(self.h, C.byref(r)))
+        return r
+
+    def rain_spawn(self):
+        """RainManager.add_random_rain() between ticks (the /spawn_rain handler)."""
+        self._chk(self._f("rain_spawn")(self.h))
 
     def num_blocks(self) -> int:
         return self._chk(self._f("num_blocks")(self.h))

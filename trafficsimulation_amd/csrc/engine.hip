@@ -780,16 +780,23 @@ __global__ void k_density_pass1(const float* t_occ, const float* t_road, int W, 
 // rain_map = union of the clouds' discs as RainManager.step saw them (rain.py:156-184): a cell is covered by a
 // cloud when (x - cx)^2 + (y - cy)^2 <= r^2 for the cloud's integer centre at its last step
 struct RainDiscs { int n; int cx[16], cy[16], r[16]; };
-__global__ void k_rain_map(int8_t* rain, int W, int H, RainDiscs D) {
+// RainManager.step (rain.py:156-184): the cells that rained at its previous step are cleared, the cells under the
+// clouds it sees now are set; everything else (a host may have written the map) stays as it is
+__global__ void k_rain_map(int8_t* rain, int W, int H, RainDiscs prev, RainDiscs D) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= W * H) return;
   const int x = i % W, y = i / W;
-  int8_t v = 0;
+  bool was = false, is = false;
+  for (int k = 0; k < prev.n; k++) {
+    const int dx = x - prev.cx[k], dy = y - prev.cy[k];
+    if (dx * dx + dy * dy <= prev.r[k] * prev.r[k]) was = true;
+  }
   for (int k = 0; k < D.n; k++) {
     const int dx = x - D.cx[k], dy = y - D.cy[k];
-    if (dx * dx + dy * dy <= D.r[k] * D.r[k]) v = 1;
+    if (dx * dx + dy * dy <= D.r[k] * D.r[k]) is = true;
   }
-  rain[i] = v;
+  if (is) rain[i] = 1;
+  else if (was) rain[i] = 0;
 }
 
 // rank[slot] = position of the slot in the shuffled key order
@@ -1041,6 +1048,7 @@ struct ts_engine {
   std::vector<Rain> rains_all;   // indexed by host-agent id - 1 (id 0 is the manager)
   std::vector<int> rains;        // city_model.rains: ids of live clouds in list order
   bool rain_manager = false;
+  RainDiscs prev_discs{};         // what the manager saw at its previous step (RainManager._prev_raining)
   int rain_counter = 0, rain_cooldown_left = 0;
   int n_host_agents = 0;         // manager + clouds ever created (hslot entries)
   int cap_hslot = 0;
@@ -2437,7 +2445,10 @@ int tick(E* e) {
     }
     if (e->hint[3]) return fail(e, e->hint[3], "device-side error: a vehicle sits on its target during decide (start == goal is not supported)");
     if (discs.n >= 0)   // RainManager.step ran: rain_map is exactly the union of the discs it saw
-      hipLaunchKernelGGL(k_rain_map, dim3(nblk((long long)e->N)), dim3(BLK), 0, st, d.rain, e->W, e->H, discs);
+    {
+      hipLaunchKernelGGL(k_rain_map, dim3(nblk((long long)e->N)), dim3(BLK), 0, st, d.rain, e->W, e->H, e->prev_discs, discs);
+      e->prev_discs = discs;
+    }
     e->C.agent_steps += sched_vehicles_at_shuffle;
     const int vehicle_deaths = e->hint[1];
     const int deaths = vehicle_deaths + host_deaths;
@@ -3204,6 +3215,19 @@ int ts_download_blocks(ts_handle e, double* rows) {
   if (!e || !rows) return TS_E_INVALID;
   for (size_t b = 0; b < e->blocks.size(); b++) { rows[2 * b] = e->blocks[b].food; rows[2 * b + 1] = e->blocks[b].waste; }
   return TS_OK;
+}
+int ts_rain_info(ts_handle e, TsRainInfo* out) {
+  if (!e || !out) return TS_E_INVALID;
+  out->has_manager = e->rain_manager; out->n_rains = (int32_t)e->rains.size();
+  out->cooldown = e->rain_cooldown_left; out->counter = e->rain_counter;
+  return TS_OK;
+}
+int ts_rain_spawn(ts_handle e) {
+  if (!e) return TS_E_INVALID;
+  if (!e->rain_manager) return fail(e, TS_E_STATE, "no RainManager is scheduled");
+  if (!e->rng_global.seeded()) return fail(e, TS_E_STATE, "seed the global stream first");
+  HIPOK(hipStreamSynchronize(e->stream));
+  return rain_add_random(e);
 }
 int ts_counters(ts_handle e, TsCounters* out) {
   if (!e || !out) return TS_E_INVALID;
