@@ -341,6 +341,11 @@ int ts_download_groups(ts_handle h, int32_t* rows); /* [G][TS_G_NFIELDS] */
 int ts_num_blocks(ts_handle h);
 int ts_download_blocks(ts_handle h, double* rows);
 int ts_counters(ts_handle h, TsCounters* out);
+/* CreateServiceVehicleHandler (visualization/ui_modules/vehicle_control.py:182-206): ServiceVehicleAgent(vid, model,
+ * entrance, sv_type) created from the UI between ticks - vehicle_service.py:19-41 as it is, without the generator's id
+ * draw (the handler numbers its vehicles itself).  service_type: TS_TRIP_SERVICE_FOOD / TS_TRIP_SERVICE_WASTE.
+ * Needs the block tables of ts_set_traffic_generator. */
+int ts_add_service_vehicle(ts_handle h, int32_t x, int32_t y, int32_t service_type);
 /* RainControl card and the /spawn_rain handler (visualization/ui_modules/rain_control.py:22-73):
  * len(model.rains), RainManager.cooldown / .counter, and RainManager.add_random_rain() called between ticks
  * (rain.py:100-148: draws from the global stream, appends the cloud to city_model.rains and to the schedule). */

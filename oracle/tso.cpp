@@ -523,7 +523,7 @@ void remove_vehicle(E* e, int vid) {  // city_model.py:1920-1941
     if (v.svc_type == TS_TRIP_SERVICE_FOOD) e->C.live_service_food--;
     else if (v.svc_type == TS_TRIP_SERVICE_WASTE) e->C.live_service_waste--;
   }
-  if (v.svc_type) e->gen.sv_live[(v.svc_type == TS_TRIP_SERVICE_FOOD ? 0 : e->gen.T.total_service_vehicles_food) + v.svc_id] = 0;
+  if (v.svc_type && v.svc_id >= 0) e->gen.sv_live[(v.svc_type == TS_TRIP_SERVICE_FOOD ? 0 : e->gen.T.total_service_vehicles_food) + v.svc_id] = 0;
   v.alive = false; v.pos = -1;
 }
 
@@ -1210,12 +1210,10 @@ void generate_day(E* e, int day_idx) {
 
 
 // _spawn for service trips (dynamic_traffic_generator.py:419-430) + ServiceVehicleAgent.__init__ (vehicle_service.py:19-41)
-void spawn_service(E* e, const Trip& t) {
+// `id` = index into the fleet's id pool, -1 for a vehicle the UI created with an id of its own
+void spawn_service_at(E* e, int origin, int kind, int id) {
   Generator& G = e->gen;
-  const bool food = t.kind == TS_TRIP_SERVICE_FOOD;
-  if (food) e->C.created_service_food++; else e->C.created_service_waste++;
-  const int pool = food ? G.T.total_service_vehicles_food : G.T.total_service_vehicles_waste;
-  const int id = (int)e->rng_global.randbelow((uint32_t)pool);   // vid = random.choice(pool)
+  const bool food = kind == TS_TRIP_SERVICE_FOOD;
   // _find_initial_target (62-83): `attempt` is never advanced, so only valid_blocks[0] is ever tried
   int blk = -1;
   for (size_t b = 0; b < G.blocks.size(); b++)
@@ -1234,24 +1232,34 @@ void spawn_service(E* e, const Trip& t) {
     target = G.hw_out[0];
     phase = 2;
   }
-  char& live = G.sv_live[(food ? 0 : G.T.total_service_vehicles_food) + id];
-  if (live) {   // BaseScheduler.add raises on a unique_id that is already scheduled (Mesa <= 2.1)
-    e->fatal = TS_E_UNSUPPORTED;
-    e->err = "service vehicle id drawn while a vehicle with that id is still live (the scheduler raises in the reference)";
-    return;
+  if (id >= 0) {
+    char& live = G.sv_live[(food ? 0 : G.T.total_service_vehicles_food) + id];
+    if (live) {   // BaseScheduler.add raises on a unique_id that is already scheduled (Mesa <= 2.1)
+      e->fatal = TS_E_UNSUPPORTED;
+      e->err = "service vehicle id drawn while a vehicle with that id is still live (the scheduler raises in the reference)";
+      return;
+    }
+    live = 1;
   }
-  int32_t s[2] = {t.origin % e->W, t.origin / e->W}, g[2] = {target % e->W, target / e->W};
+  int32_t s[2] = {origin % e->W, origin / e->W}, g[2] = {target % e->W, target / e->W};
   int32_t pop = TS_POP_THROUGH;
-  e->svc_pending_type = t.kind;
+  e->svc_pending_type = kind;
   tso_add_vehicles(e, 1, s, g, &pop, nullptr, nullptr);
   e->svc_pending_type = 0;
   Vehicle& v = e->veh.back();
-  live = 1;
   v.svc_id = id; v.svc_phase = phase; v.current_block = blk;
   v.max_load = food ? G.T.service_max_load_food : G.T.service_max_load_waste;
   v.current_load = food ? v.max_load : 0.0;
   v.remove_on_arrival = false;
   v.service_ticks = 0;
+}
+void spawn_service(E* e, const Trip& t) {
+  Generator& G = e->gen;
+  const bool food = t.kind == TS_TRIP_SERVICE_FOOD;
+  if (food) e->C.created_service_food++; else e->C.created_service_waste++;
+  const int pool = food ? G.T.total_service_vehicles_food : G.T.total_service_vehicles_waste;
+  const int id = (int)e->rng_global.randbelow((uint32_t)pool);   // vid = random.choice(pool)
+  spawn_service_at(e, t.origin, t.kind, id);
 }
 
 // DynamicTrafficAgent.step (dynamic_traffic_generator.py:153-194) + _spawn (398-416)
@@ -1777,6 +1785,14 @@ int tso_download_blocks(ts_handle e, double* rows) {
   if (!e || !rows) return TS_E_INVALID;
   for (size_t b = 0; b < e->gen.blocks.size(); b++) { rows[2 * b] = e->gen.blocks[b].food; rows[2 * b + 1] = e->gen.blocks[b].waste; }
   return TS_OK;
+}
+int tso_add_service_vehicle(ts_handle e, int32_t x, int32_t y, int32_t service_type) {
+  if (!e || x < 0 || x >= e->W || y < 0 || y >= e->H) return TS_E_INVALID;
+  if (service_type != TS_TRIP_SERVICE_FOOD && service_type != TS_TRIP_SERVICE_WASTE) return fail(e, TS_E_INVALID, "service_type");
+  if (e->gen.blocks.empty()) return fail(e, TS_E_STATE, "service vehicles need the block tables (ts_set_traffic_generator)");
+  if (e->fatal) return e->fatal;
+  spawn_service_at(e, y * e->W + x, service_type, -1);
+  return e->fatal;
 }
 int tso_rain_info(ts_handle e, TsRainInfo* out) {
   if (!e || !out) return TS_E_INVALID;

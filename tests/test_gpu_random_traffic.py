@@ -62,7 +62,24 @@ def run_case(case, make_engines, ticks):
     a, b = apis
     ctx0 = f"case {case} ({WORLDS[case % len(WORLDS)]}, pops {pops}, fleet {svc['service_food']}/{svc['service_waste']})"
     raised = None
+    ui = np.random.default_rng(77 + case)
+    hw_in = np.asarray(tr["highway_entrances_xy"]).reshape(-1, 2)
     for t in range(ticks):
+        if t % 17 == 5 and ui.integers(3) == 0 and len(hw_in):
+            # the UI's CreateServiceVehicleHandler between two ticks (vehicle_control.py:182-206)
+            x, y = hw_in[ui.integers(len(hw_in))]
+            kind = capi.TRIP_SERVICE_FOOD if ui.integers(2) else capi.TRIP_SERVICE_WASTE
+            rcs = []
+            for e in (a, b):
+                try:
+                    e.add_service_vehicle(int(x), int(y), kind)
+                    rcs.append(None)
+                except capi.EngineError as ex:
+                    rcs.append(ex.code)
+            assert rcs[0] == rcs[1], f"{ctx0} tick {t}: add_service_vehicle {rcs}"
+            if rcs[0] is not None:
+                raised = t
+                break
         errs = []
         for e in (a, b):
             try:

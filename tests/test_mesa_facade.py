@@ -127,3 +127,35 @@ def test_facade_rain_control_over_oracle(oracle):
         m.step()
     assert m.rain_map.sum() > 0 or len(m.rains) >= 1
     assert m.schedule.get_agent_count() >= n_sched - 1   # the cloud is a scheduled agent until it leaves the map
+
+
+def test_facade_ui_vehicle_handlers_over_oracle(oracle):
+    """CreateVehicleHandler / CreateServiceVehicleHandler (vehicle_control.py:182-252): get_start_blocks,
+    get_valid_exits (empty for a highway entrance, like the reference), VehicleAgent(vid, model, start, target) and
+    ServiceVehicleAgent(vid, model, entrance, sv_type) between ticks."""
+    import json
+    from trafficsimulation_amd.mesa_api import ServiceVehicleAgent
+    tr = load_trace(trace_path("service_64_s15"))
+    dta = json.loads(str(tr["dta_params"]))
+    m = CityModel.from_tables(tr, seed=1, defaults=tr["defaults_json"], engine=oracle, traffic=dict(dta, P_int=0, P_thr=0,
+                              service_food=0, service_waste=0),
+                              global_state=tr["global_rng_before_day0"], sched_state=tr["sched_rng_initial"])
+    starts = m.get_start_blocks()
+    be = m.block_entrances[0]
+    exits = m.get_valid_exits(be)
+    assert be not in exits and len(exits) == len(m.block_entrances) - 1 + len(m.highway_exits)
+    assert m.get_valid_exits(m.highway_entrances[0]) == []
+    assert m.get_valid_exits(m.cell(0, 0)) == [] and be in starts
+    v = VehicleAgent("V1", m, be, exits[0])
+    sv = ServiceVehicleAgent("SV1", m, m.highway_entrances[0], "Food")
+    sw = ServiceVehicleAgent("SV2", m, m.highway_entrances[1], "Waste")
+    assert sv.phase == "to_block" and sv.current_load == sv.max_load == 50.0 and sw.current_load == 0.0
+    assert sv.get_vehicle_type_name() == "FoodServiceVehicle" and sv.population_type == "through"
+    for _ in range(150):
+        m.step()
+    live = m.active_vehicle_agents
+    assert all(x in (v, sv, sw) for x in live)
+    stats = m.dynamic_traffic_generator.cached_stats
+    assert stats["live_service_food"] + stats["live_service_waste"] == sum(1 for x in live if x is not v)
+    with pytest.raises(Exception):
+        ServiceVehicleAgent("SV1", m, m.highway_entrances[0], "Food")

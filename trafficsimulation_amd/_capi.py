@@ -220,6 +220,7 @@ class CApi:
         f("download_groups").argtypes = [C.c_void_p, C.c_void_p]
         f("download_blocks").argtypes = [C.c_void_p, C.c_void_p]
         f("rain_info").argtypes = [C.c_void_p, C.POINTER(TsRainInfo)]
+        f("add_service_vehicle").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         f("download_vehicle_meta").argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         f("download_service_vehicles").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         f("counters").argtypes = [C.c_void_p, C.POINTER(TsCounters)]
@@ -482,6 +483,10 @@ class CApi:
         blk = np.zeros(cap, dtype=np.int32)
         n = self._chk(self._f("download_service_vehicles")(self.h, idx.ctypes.data, loads.ctypes.data, blk.ctypes.data, cap))
         return idx[:n], loads[:n], blk[:n]
+
+    def add_service_vehicle(self, x: int, y: int, service_type: int):
+        """ServiceVehicleAgent(vid, model, entrance, sv_type) from the UI (vehicle_control.py:182-206)."""
+        self._chk(self._f("add_service_vehicle")(self.h, int(x), int(y), int(service_type)))
 
     def rain_info(self) -> TsRainInfo:
         r = TsRainInfo()

@@ -1900,12 +1900,10 @@ int svc_finish(E* e, ts_engine::SvcVeh& v) {
 }
 
 // _spawn for service trips (dynamic_traffic_generator.py:419-430) + ServiceVehicleAgent.__init__ (vehicle_service.py:19-41)
-int spawn_service(E* e, const ts_engine::Trip& t) {
+// `id` = index into the fleet's id pool, -1 for a vehicle the UI created with an id of its own
+int spawn_service_at(E* e, int origin, int kind, int id) {
   auto& G = e->gen;
-  const bool food = t.kind == TS_TRIP_SERVICE_FOOD;
-  if (food) e->C.created_service_food++; else e->C.created_service_waste++;
-  const int pool = food ? G.T.total_service_vehicles_food : G.T.total_service_vehicles_waste;
-  const int id = (int)e->rng_global.randbelow((uint32_t)pool);   // vid = random.choice(pool)
+  const bool food = kind == TS_TRIP_SERVICE_FOOD;
   // _find_initial_target (62-83): `attempt` is never advanced, so only valid_blocks[0] is ever tried
   int blk = -1;
   for (size_t b = 0; b < e->blocks.size(); b++)
@@ -1923,25 +1921,39 @@ int spawn_service(E* e, const ts_engine::Trip& t) {
     target = G.hw_out[0];
     phase = 2;
   }
-  char& live = e->sv_live[(size_t)(food ? 0 : G.T.total_service_vehicles_food) + id];
-  if (live) {   // BaseScheduler.add raises on a unique_id that is already scheduled (Mesa <= 2.1)
-    e->fatal = TS_E_UNSUPPORTED;
-    return fail(e, TS_E_UNSUPPORTED, "service vehicle id drawn while a vehicle with that id is still live (the scheduler raises in the reference)");
+  if (id >= 0) {
+    char& live = e->sv_live[(size_t)(food ? 0 : G.T.total_service_vehicles_food) + id];
+    if (live) {   // BaseScheduler.add raises on a unique_id that is already scheduled (Mesa <= 2.1)
+      e->fatal = TS_E_UNSUPPORTED;
+      return fail(e, TS_E_UNSUPPORTED, "service vehicle id drawn while a vehicle with that id is still live (the scheduler raises in the reference)");
+    }
+    live = 1;
   }
   if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
-  int rc = add_vehicle_planned(e, t.origin, target, TS_POP_THROUGH);
+  if (!e->d.arr) {   // first service vehicle of this engine: the record buffer the kernels report arrivals in
+    e->d.arr_cap = 1 << 16;
+    HIPOK(dalloc(e, &e->d.arr, (size_t)e->d.arr_cap * 3));
+  }
+  int rc = add_vehicle_planned(e, origin, target, TS_POP_THROUGH);
   if (rc) return rc;
   const int vid = e->n_vehicles_total - 1;
   hipLaunchKernelGGL(k_flags_or, dim3(1), dim3(64), 0, e->stream, e->d, vid, (int)(VF_SVC | VF_KEEP | (phase == 0 ? VF_TOBLOCK : 0)));
-  live = 1;
   ts_engine::SvcVeh v;
-  v.vid = vid; v.type = t.kind; v.id = id; v.block = blk;
+  v.vid = vid; v.type = kind; v.id = id; v.block = blk;
   v.max_load = food ? G.T.service_max_load_food : G.T.service_max_load_waste;
   v.load = food ? v.max_load : 0.0;
-  v.phase = phase; v.ticks = 0; v.pos = t.origin; v.target = target;
+  v.phase = phase; v.ticks = 0; v.pos = origin; v.target = target;
   e->svc.push_back(v);
   if (food) e->C.live_service_food++; else e->C.live_service_waste++;
   return TS_OK;
+}
+int spawn_service(E* e, const ts_engine::Trip& t) {
+  auto& G = e->gen;
+  const bool food = t.kind == TS_TRIP_SERVICE_FOOD;
+  if (food) e->C.created_service_food++; else e->C.created_service_waste++;
+  const int pool = food ? G.T.total_service_vehicles_food : G.T.total_service_vehicles_waste;
+  const int id = (int)e->rng_global.randbelow((uint32_t)pool);   // vid = random.choice(pool)
+  return spawn_service_at(e, t.origin, t.kind, id);
 }
 
 // DynamicTrafficAgent.step (153-194) and _spawn (398-416), executed at the agent's place in the shuffled order:
@@ -2377,7 +2389,7 @@ int tick(E* e) {
           if (ev.kind == 2) svc_start(e, e->svc[k]);
           else {
             auto& v = e->svc[k];
-            e->sv_live[(size_t)(v.type == TS_TRIP_SERVICE_FOOD ? 0 : e->gen.T.total_service_vehicles_food) + v.id] = 0;
+            if (v.id >= 0) e->sv_live[(size_t)(v.type == TS_TRIP_SERVICE_FOOD ? 0 : e->gen.T.total_service_vehicles_food) + v.id] = 0;
             if (v.type == TS_TRIP_SERVICE_FOOD) e->C.live_service_food--; else e->C.live_service_waste--;
             e->svc.erase(e->svc.begin() + k);
           }
@@ -3215,6 +3227,13 @@ int ts_download_blocks(ts_handle e, double* rows) {
   if (!e || !rows) return TS_E_INVALID;
   for (size_t b = 0; b < e->blocks.size(); b++) { rows[2 * b] = e->blocks[b].food; rows[2 * b + 1] = e->blocks[b].waste; }
   return TS_OK;
+}
+int ts_add_service_vehicle(ts_handle e, int32_t x, int32_t y, int32_t service_type) {
+  if (!e || x < 0 || x >= e->W || y < 0 || y >= e->H) return TS_E_INVALID;
+  if (service_type != TS_TRIP_SERVICE_FOOD && service_type != TS_TRIP_SERVICE_WASTE) return fail(e, TS_E_INVALID, "service_type");
+  if (e->blocks.empty()) return fail(e, TS_E_STATE, "service vehicles need the block tables (ts_set_traffic_generator)");
+  if (e->fatal) return e->fatal;
+  return spawn_service_at(e, y * e->W + x, service_type, -1);
 }
 int ts_rain_info(ts_handle e, TsRainInfo* out) {
   if (!e || !out) return TS_E_INVALID;
