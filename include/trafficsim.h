@@ -341,6 +341,13 @@ int ts_download_groups(ts_handle h, int32_t* rows); /* [G][TS_G_NFIELDS] */
 int ts_num_blocks(ts_handle h);
 int ts_download_blocks(ts_handle h, double* rows);
 int ts_counters(ts_handle h, TsCounters* out);
+/* IntersectionLightGroup.get_opposite_traffic_lights() (intersection_light_group.py:303-307), which the UI's
+ * SetOppGo / SetOppStop handlers call (ui_modules/traffic_light_control.py:336-362): while the group's opposite_pairs
+ * are still empty it re-runs populate_links(), after which the NEIGHBOR_* controllers read the re-populated
+ * neighbour table (TsLightTables::g_neighbors instead of g_neighbors_ctor).  repopulate != 0 performs that side
+ * effect; the return value is 1 if the group's links have been re-populated (by this call, an earlier one or the
+ * group's first phase change), else 0. */
+int ts_group_links(ts_handle h, int32_t group, int32_t repopulate);
 /* CreateServiceVehicleHandler (visualization/ui_modules/vehicle_control.py:182-206): ServiceVehicleAgent(vid, model,
  * entrance, sv_type) created from the UI between ticks - vehicle_service.py:19-41 as it is, without the generator's id
  * draw (the handler numbers its vehicles itself).  service_type: TS_TRIP_SERVICE_FOOD / TS_TRIP_SERVICE_WASTE.

@@ -1786,6 +1786,11 @@ int tso_download_blocks(ts_handle e, double* rows) {
   for (size_t b = 0; b < e->gen.blocks.size(); b++) { rows[2 * b] = e->gen.blocks[b].food; rows[2 * b + 1] = e->gen.blocks[b].waste; }
   return TS_OK;
 }
+int tso_group_links(ts_handle e, int32_t group, int32_t repopulate) {
+  if (!e || group < 0 || group >= (int)e->groups.size()) return TS_E_INVALID;
+  if (repopulate) e->groups[group].links_repopulated = true;
+  return e->groups[group].links_repopulated ? 1 : 0;
+}
 int tso_add_service_vehicle(ts_handle e, int32_t x, int32_t y, int32_t service_type) {
   if (!e || x < 0 || x >= e->W || y < 0 || y >= e->H) return TS_E_INVALID;
   if (service_type != TS_TRIP_SERVICE_FOOD && service_type != TS_TRIP_SERVICE_WASTE) return fail(e, TS_E_INVALID, "service_type");

@@ -42,7 +42,8 @@ def test_random_call_sequences(case):
     if with_manager:   # a RainManager in front of the clock agent; host rain-map writes are then overwritten by its step
         kinds = list(np.asarray(tb["schedule_kinds0"]))
         tb["schedule_kinds0"] = np.asarray(kinds[:-1] + [2] + kinds[-1:], dtype=np.int8)
-    d = {"TRAFFIC_LIGHT_AGENT_ALGORITHM": str(rng.choice(["QUEUE_ACTUATED", "FIXED_TIME", "DISABLED"])),
+    d = {"TRAFFIC_LIGHT_AGENT_ALGORITHM": str(rng.choice(["QUEUE_ACTUATED", "FIXED_TIME", "DISABLED", "NEIGHBOR_GREEN_WAVE",
+                                                          "NEIGHBOR_PRESSURE_CONTROL"])),
          "RAIN_ENABLED": True, "RAIN_SPEED_REDUCTION": 2, "VEHICLE_MALFUNCTION_CHANCE": float(rng.choice([1e-7, 0.004])),
          "VEHICLE_SIDESWIPE_COLLISION_CHANCE": float(rng.choice([1e-9, 0.1])), "PATHFINDING_COOLDOWN": int(rng.choice([2, 5]))}
     a, b = new_engine(), pyoracle.load()
@@ -53,10 +54,11 @@ def test_random_call_sequences(case):
     s, g, off, dirs = pool
     used = 0
     lights = np.asarray(tb["light_xy"]).reshape(-1, 2)
+    n_groups = len(np.asarray(tb["g_light_off"])) - 1
     coff, cxy = np.asarray(tb["light_ctrl_off"]), np.asarray(tb["light_ctrl_xy"]).reshape(-1, 2)
     for op_i in range(60):
         op = rng.choice(["step", "step", "step", "spawn_paths", "spawn_plan", "stop", "rain", "seed_int", "seed_state",
-                         "rain_spawn"])
+                         "rain_spawn", "group_links"])
         ctx = f"case {case} op {op_i} ({op})"
         if op == "step":
             n = int(rng.integers(1, 6))
@@ -93,6 +95,11 @@ def test_random_call_sequences(case):
                 a.rain_spawn(), b.rain_spawn()
             ib, ia = b.rain_info(), a.rain_info()
             assert (ia.n_rains, ia.cooldown, ia.counter) == (ib.n_rains, ib.cooldown, ib.counter), ctx
+        elif op == "group_links" and n_groups:
+            # get_opposite_traffic_lights() from the UI re-populates a group's links (matters to the NEIGHBOR_* controllers)
+            gi = int(rng.integers(n_groups))
+            assert a.group_links(gi, False) == b.group_links(gi, False), ctx
+            assert a.group_links(gi, True) and b.group_links(gi, True)
         elif op == "seed_int":
             which = int(rng.integers(2))
             v = int(rng.integers(1, 2 ** 40))

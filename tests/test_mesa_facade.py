@@ -159,3 +159,28 @@ def test_facade_ui_vehicle_handlers_over_oracle(oracle):
     assert stats["live_service_food"] + stats["live_service_waste"] == sum(1 for x in live if x is not v)
     with pytest.raises(Exception):
         ServiceVehicleAgent("SV1", m, m.highway_entrances[0], "Food")
+
+
+def test_facade_light_group_links_over_oracle(oracle):
+    """What the UI's group handlers call (traffic_light_control.py:300-400): get_opposite_traffic_lights() with its
+    populate_links() side effect, get_neighbor_groups(), set_all_*_with_neighbors()."""
+    tr = load_trace(trace_path("lights_npress_96_s6"))
+    m = CityModel.from_tables(tr, seed=1, defaults=tr["defaults_json"], engine=oracle,
+                              global_state=tr["global_rng_after_worldgen"], sched_state=tr["sched_rng_initial"])
+    g = m.intersection_light_groups[3]
+    ctor = np.asarray(tr["g_neighbors_ctor"]).reshape(-1, 4, 2)[3]
+    full = np.asarray(tr["g_neighbors"]).reshape(-1, 4, 2)[3]
+    assert not m.engine.group_links(3)
+    assert len(g.get_neighbor_groups()) == int(np.sum((ctor[:, 0] >= 0) & (ctor[:, 1] >= 0)))
+    pairs = g.get_opposite_traffic_lights()
+    assert set(pairs) == {"N-S", "W-E"} and all(tl in g.traffic_lights for ax in pairs.values() for tl in ax)
+    assert m.engine.group_links(3)            # the call re-populated the group's links
+    nb = g.get_neighbor_groups()
+    assert len(nb) == int(np.sum((full[:, 0] >= 0) & (full[:, 1] >= 0)))
+    g.set_all_stop_with_neighbors()
+    for grp in [g] + list(nb.values()):
+        for tl in grp.traffic_lights:
+            assert m.stop_map[tl.position[1], tl.position[0]] == 1
+    m.step()
+    with pytest.raises(NotImplementedError):
+        g.get_intermediate_groups()

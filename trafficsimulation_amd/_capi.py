@@ -221,6 +221,7 @@ class CApi:
         f("download_blocks").argtypes = [C.c_void_p, C.c_void_p]
         f("rain_info").argtypes = [C.c_void_p, C.POINTER(TsRainInfo)]
         f("add_service_vehicle").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        f("group_links").argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         f("download_vehicle_meta").argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         f("download_service_vehicles").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         f("counters").argtypes = [C.c_void_p, C.POINTER(TsCounters)]
@@ -483,6 +484,10 @@ class CApi:
         blk = np.zeros(cap, dtype=np.int32)
         n = self._chk(self._f("download_service_vehicles")(self.h, idx.ctypes.data, loads.ctypes.data, blk.ctypes.data, cap))
         return idx[:n], loads[:n], blk[:n]
+
+    def group_links(self, group: int, repopulate: bool = False) -> bool:
+        """get_opposite_traffic_lights()'s side effect / state (see ts_group_links)."""
+        return bool(self._chk(self._f("group_links")(self.h, int(group), int(bool(repopulate)))))
 
     def add_service_vehicle(self, x: int, y: int, service_type: int):
         """ServiceVehicleAgent(vid, model, entrance, sv_type) from the UI (vehicle_control.py:182-206)."""

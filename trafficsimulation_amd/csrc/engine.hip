@@ -3228,6 +3228,14 @@ int ts_download_blocks(ts_handle e, double* rows) {
   for (size_t b = 0; b < e->blocks.size(); b++) { rows[2 * b] = e->blocks[b].food; rows[2 * b + 1] = e->blocks[b].waste; }
   return TS_OK;
 }
+int ts_group_links(ts_handle e, int32_t group, int32_t repopulate) {
+  if (!e || group < 0 || group >= e->d.G) return TS_E_INVALID;
+  int v = 0;
+  if (repopulate) { v = 1; HIPOK(hipMemcpy(e->d.gs_repop + group, &v, 4, hipMemcpyHostToDevice)); return 1; }
+  HIPOK(hipStreamSynchronize(e->stream));
+  HIPOK(hipMemcpy(&v, e->d.gs_repop + group, 4, hipMemcpyDeviceToHost));
+  return v ? 1 : 0;
+}
 int ts_add_service_vehicle(ts_handle e, int32_t x, int32_t y, int32_t service_type) {
   if (!e || x < 0 || x >= e->W || y < 0 || y >= e->H) return TS_E_INVALID;
   if (service_type != TS_TRIP_SERVICE_FOOD && service_type != TS_TRIP_SERVICE_WASTE) return fail(e, TS_E_INVALID, "service_type");
