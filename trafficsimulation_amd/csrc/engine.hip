@@ -31,1404 +31,13 @@
 
 #include "dev.h"
 #include "astar.h"
+#include "kernels.h"
+#include "host_state.h"
+#include "host_shuffle.h"
+#include "host_agents.h"
 
 namespace {
 
-// ---------------------------------------------------------------------------------------------
-// decide, part 1 (pure): which draws of the global MT19937 stream does each vehicle consume?
-// step_decide prologue, vehicle_base.py:616-643 with _tick_stranded 552-565, _check_malfunction
-// 608-610, _check_sideswipe_collision 567-605, _is_at_stopped_cell 121-127, _compute_speed 94-107.
-// ---------------------------------------------------------------------------------------------
-__global__ void k_decide_pre(Dev d, TsParams P, int start, int n_active) {
-  int i = start + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_active) return;
-  int vid = d.active[i];
-  uint8_t F = 0;
-  int cand = -1;
-  if (vid >= 0) {
-    uint16_t f = d.flags[vid];
-    bool sb = (f & (VF_COLL | VF_MALF)) != 0;
-    bool still = sb && (d.stranded_left[vid] - 1 > 0);
-    // strandedness before / after this vehicle's own step_decide, for k_decide_main's blocker checks
-    d.st_before[vid] = sb;
-    d.st_after[vid] = still || !P.malfunction_active;  // `not ACTIVE or ...`: everyone malfunctions (609)
-    if (!still && P.malfunction_active) {
-      F |= F_DRAW_MALF;
-      const int W = d.W, H = d.H;
-      int pos = d.pos[vid];
-      int dir = d.dir[vid];
-      if (P.sideswipe_active && dir >= 0) {
-        int x = pos % W, y = pos / W;
-        const int opposite = (dir + 2) & 3;
-        for (int k = 0; k < 2 && cand < 0; k++) {
-          int ld = k == 0 ? ((dir + 3) & 3) : ((dir + 1) & 3);  // left, then right
-          int nx = x + (ld == 1) - (ld == 3), ny = y + (ld == 0) - (ld == 2);
-          if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
-          for (int ag = d.cell[ny * W + nx].veh; ag >= 0; ag = d.next_in_cell[ag]) {
-            uint16_t af = d.flags[ag];
-            bool earlier = d.active_idx[ag] < i;
-            bool ag_sb = (af & (VF_COLL | VF_MALF)) != 0;
-            bool ag_str = earlier ? (d.ev[ag] ? true : ((ag_sb && d.stranded_left[ag] - 1 > 0) || !P.malfunction_active)) : ag_sb;
-            bool cs_pos = earlier ? (!ag_str && d.cell[d.pos[ag]].stop != 1) : (d.cur_speed[ag] > 0);
-            if (!cs_pos || (af & (VF_STUCK | VF_PARKED)) || ag_str) continue;
-            if (earlier && (af & VF_KEEP) && d.pos[ag] == d.target[ag]) continue;   // it parked inside its own step_decide
-            if (d.dir[ag] != opposite) continue;
-            cand = ag;
-            break;
-          }
-        }
-        if (cand >= 0) F |= F_DRAW_SWIPE;
-      }
-      if (d.cell[pos].stop != 1 && d.base_speed[vid] == 0) F |= F_DRAW_SPEED;
-    }
-  }
-  d.F[i] = F;
-  d.cand[i] = cand;
-}
-
-// _set_malfunction / _set_collision (vehicle_base.py:534-550) for the (rare) events the host scan finds.
-// ev: 1 = stranded at its own decide point (early exit there); 2 = hit by a later vehicle after deciding;
-// 3 = hit before its own turn (it will find itself stranded).  ev_idx = decide-order index of the event.
-__global__ void k_apply_event(Dev d, TsParams P, int vid, int is_collision, int partner, int my_idx) {
-  if (threadIdx.x || blockIdx.x) return;
-  {
-    // the vehicle reached its draws, so a stranding it still carried from earlier ticks expired in this very
-    // step_decide (_tick_stranded, vehicle_base.py:556-564): do that bookkeeping before the new stranding
-    uint16_t f0 = d.flags[vid];
-    if (f0 & VF_COLL) atomicAdd((unsigned long long*)&d.cnt->collisions, (unsigned long long)-1LL);
-    if (f0 & VF_MALF) atomicAdd((unsigned long long*)&d.cnt->malfunctions, (unsigned long long)-1LL);
-    d.flags[vid] = f0 & ~(VF_COLL | VF_MALF);
-  }
-  if (!is_collision) {
-    d.flags[vid] = (d.flags[vid] | VF_MALF) & ~VF_COLL;
-    d.stranded_left[vid] = P.malfunction_duration;
-    d.base_speed[vid] = 0; d.cur_speed[vid] = 0;
-    d.ev[vid] = 1; d.ev_idx[vid] = my_idx;
-    atomicAdd((unsigned long long*)&d.cnt->malfunctions, 1ULL);
-  } else {
-    d.flags[vid] = (d.flags[vid] | VF_COLL) & ~VF_MALF;
-    d.stranded_left[vid] = P.sideswipe_duration;
-    d.base_speed[vid] = 0; d.cur_speed[vid] = 0;
-    d.ev[vid] = 1; d.ev_idx[vid] = my_idx;
-    {
-      // an earlier partner that was a valid candidate had any old stranding expire in its own step_decide of
-      // this tick; its stored flags still show it because k_decide_main has not run yet
-      uint16_t pf = d.flags[partner];
-      if (pf & VF_COLL) atomicAdd((unsigned long long*)&d.cnt->collisions, (unsigned long long)-1LL);
-      if (pf & VF_MALF) atomicAdd((unsigned long long*)&d.cnt->malfunctions, (unsigned long long)-1LL);
-    }
-    d.flags[partner] = (d.flags[partner] | VF_COLL) & ~VF_MALF;
-    d.stranded_left[partner] = P.sideswipe_duration;
-    if (d.active_idx[partner] < my_idx) {
-      // already decided this tick: k_decide_main still needs its pre-collision base_speed to reproduce that
-      // decision, and zeroes base/current speed itself afterwards (ev == 2)
-      d.ev[partner] = 2;
-    } else {
-      d.ev[partner] = 3;
-      d.base_speed[partner] = 0; d.cur_speed[partner] = 0;
-    }
-    d.ev_idx[partner] = my_idx;
-    atomicAdd((unsigned long long*)&d.cnt->collisions, 2ULL);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// move phase
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void claim(const Dev& d, int cell, int plane, uint32_t key) { atomicMin(&d.cell[cell].claim[plane], key); }
-
-__device__ __forceinline__ bool group_reads_out(const TsParams& P) {
-  return P.light_algorithm == TS_LIGHTS_PRESSURE_CONTROL || P.light_algorithm == TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL;
-}
-__device__ __forceinline__ bool group_reads_neighbors(const TsParams& P) {
-  return P.light_algorithm == TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL || P.light_algorithm == TS_LIGHTS_NEIGHBOR_GREEN_WAVE;
-}
-
-// Every unresolved agent announces the cells it will read/write: cw_* = min rank of writers,
-// cr_* = min rank of readers.  Keys carry an epoch prefix that DEcreases every round, so atomicMin
-// makes stale entries of earlier rounds lose and nothing has to be cleared.
-// `list` == nullptr: every schedule slot (first round); otherwise the slots left unresolved by the previous round.
-__global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix, const int32_t* list, const int* list_n,
-                             uint32_t rank_limit, int group_cells_elsewhere) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int s;
-  if (list) { if (t >= *list_n) return; s = list[t]; } else { s = t; if (s >= n_sched) return; }
-  if (d.resolved[s] || d.rank[s] >= rank_limit) return;   // rank_limit: agents behind a host-side agent wait for it
-  const int8_t kind = d.sched_kind[s];
-  const uint32_t key = (prefix << RANK_BITS) | d.rank[s];
-  if (kind == K_VEHICLE) {
-    const int vid = d.sched_ref[s];
-    const uint16_t f = d.flags[vid];
-    const int pos = d.pos[vid];
-    if (f & VF_SERVICING) return;   // ServiceVehicleAgent.step only counts down (vehicle_service.py:43-49)
-    if (f & VF_EARLY) {
-      if (d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED) claim(d, pos, 3, key);  // tick_stuck reads stop[pos]
-      if (pos == d.target[vid]) claim(d, pos, 0, key);
-    } else {
-      const int m = d.max_steps[vid];
-      claim(d, pos, 0, key);
-      const uint32_t off = d.path_off[vid];
-      const int pcur = d.path_cur[vid];
-      int c = pos;
-      for (int k = 0; k < m; k++) {
-        c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
-        claim(d, c, 0, key);
-        if (d.G > 0) claim(d, c, 3, key);
-      }
-    }
-  } else if (kind == TS_AGENT_LIGHT_GROUP && P.light_algorithm != TS_LIGHTS_DISABLED) {
-    const int g = d.sched_ref[s];
-    if (!group_cells_elsewhere) {   // (the first round of a phase claims the cells in k_move_claim_groups)
-      for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1]; k++) claim(d, d.g_icell[k], 1, key);
-      for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1]; k++) claim(d, d.g_nsin[k], 1, key);
-      for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1]; k++) claim(d, d.g_ewin[k], 1, key);
-      if (group_reads_out(P)) {
-        for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1]; k++) claim(d, d.g_nsout[k], 1, key);
-        for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1]; k++) claim(d, d.g_ewout[k], 1, key);
-      }
-      for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1]; l++) {
-        claim(d, d.light_cell[l], 2, key);
-        for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) claim(d, d.light_ctrl[k], 2, key);
-      }
-    }
-    if (group_reads_neighbors(P)) {
-      for (int k = 0; k < 4; k++) {
-        int n1 = d.g_nb[(g * 4 + k) * 2 + 1], n2 = d.g_nb_ctor[(g * 4 + k) * 2 + 1];
-        if (n1 >= 0) atomicMin(&d.gclaim_r[n1], key);
-        if (n2 >= 0) atomicMin(&d.gclaim_r[n2], key);
-      }
-    }
-  }
-}
-
-// the cell claims of every unresolved light group below the rank limit, one thread per (cell, group, plane) pair
-__global__ void k_move_claim_groups(Dev d, uint32_t prefix, uint32_t rank_limit) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= d.gc_n) return;
-  const int s = d.g_slot[d.gc_group[j]];
-  const uint32_t rk = d.rank[s];
-  if (d.resolved[s] || rk >= rank_limit) return;
-  atomicMin(&d.cell[d.gc_cell[j]].claim[d.gc_plane[j]], (prefix << RANK_BITS) | rk);
-}
-
-__device__ __forceinline__ void cell_unlink(const Dev& d, int cell, int vid) {
-  int h = d.cell[cell].veh;
-  if (h == vid) { d.cell[cell].veh = d.next_in_cell[vid]; return; }
-  while (h >= 0 && d.next_in_cell[h] != vid) h = d.next_in_cell[h];
-  if (h >= 0) d.next_in_cell[h] = d.next_in_cell[vid];
-}
-__device__ __forceinline__ void cell_append(const Dev& d, int cell, int vid) {
-  d.next_in_cell[vid] = -1;
-  int h = d.cell[cell].veh;
-  if (h < 0) { d.cell[cell].veh = vid; return; }
-  while (d.next_in_cell[h] >= 0) h = d.next_in_cell[h];
-  d.next_in_cell[h] = vid;
-}
-
-// on_target_reached (vehicle_base.py:755-775) -> _despawn -> CityModel.remove_vehicle (city_model.py:1920-1941)
-__device__ void on_target_reached_dev(const Dev& d, const TsParams& P, int vid, int s, int pos, uint16_t& f,
-                                      double elapsed_now, int key) {
-  if (f & VF_TOBLOCK) {   // ServiceVehicleAgent.on_target_reached -> _start_service (vehicle_service.py:54-60, 85-104):
-    // park and start the load timer here; the load / block bookkeeping is host state (AR_START record)
-    if (!(f & VF_PARKED)) { f |= VF_PARKED; atomicAdd((unsigned long long*)&d.cnt->parked, 1ULL); }
-    f = (f & ~VF_TOBLOCK) | VF_SERVICING;
-    svc_record(d, key, vid, AR_START);
-    return;
-  }
-  if (P.enable_traffic) {
-    double duration = elapsed_now - d.depart[vid];
-    int pop = d.pop[vid];
-    if (pop == TS_POP_INTERNAL) {
-      atomicAdd(&d.cnt->dur_internal, duration);
-      atomicAdd((unsigned long long*)&d.cnt->dist_internal, (unsigned long long)d.steps[vid]);
-      atomicAdd((unsigned long long*)&d.cnt->completed_internal, 1ULL);
-    } else if (pop == TS_POP_THROUGH) {
-      atomicAdd(&d.cnt->dur_through, duration);
-      atomicAdd((unsigned long long*)&d.cnt->dist_through, (unsigned long long)d.steps[vid]);
-      atomicAdd((unsigned long long*)&d.cnt->completed_through, 1ULL);
-    }
-  }
-  if (!(f & VF_KEEP)) {
-    set_occ(d, pos, 0); d.cell[pos].stuck = 0;
-    cell_unlink(d, pos, vid);
-    f &= ~VF_ALIVE;
-    d.sched_kind[s] = K_DEAD;
-    d.active[d.active_idx[vid]] = -1;
-    int pop = d.pop[vid];
-    if (pop == TS_POP_INTERNAL) atomicAdd((unsigned long long*)&d.cnt->live_internal, (unsigned long long)-1LL);
-    else if (pop == TS_POP_THROUGH) atomicAdd((unsigned long long*)&d.cnt->live_through, (unsigned long long)-1LL);
-    atomicAdd(&d.cnt->deaths, 1);
-    if (f & VF_SVC) svc_record(d, key, vid, AR_DESPAWN);
-  } else if (!(f & VF_PARKED)) {
-    f |= VF_PARKED;
-    atomicAdd((unsigned long long*)&d.cnt->parked, 1ULL);
-    if (f & VF_SVC) svc_record(d, key, vid, AR_START);   // the host keeps the set of cells with a parked vehicle
-  }
-}
-
-// VehicleAgent.step with PATHFINDING_BATCHING (vehicle_base.py:666-685): _execute_movement 733-753,
-// _move_to 521-532 + CityModel.move_vehicle (city_model.py:1945-1963), tick_stuck 687-693.
-// `cells` / `recs`: the vehicle's cell and the next max_steps path cells with their records as k_move_resolve
-// loaded them for the claim test (nothing can have changed them since: that is what "safe" means); pass nullptr
-// to read them here.
-constexpr int MOVE_MAX = 8;
-__device__ __forceinline__ void vehicle_step_dev(const Dev& d, const TsParams& P, int vid, int s, double elapsed_now, int key,
-                                                 const bool pre, const int (&cells)[MOVE_MAX + 1], const uint4 (&dyn)[MOVE_MAX + 1]) {
-  uint16_t f = d.flags[vid];
-  if (f & VF_SERVICING) return;   // the countdown and _finish_service are host state
-  int pos = d.pos[vid];
-  if (!(f & VF_EARLY)) {
-    const int m = d.max_steps[vid];
-    const uint32_t off = d.path_off[vid];
-    const int pcur = d.path_cur[vid];
-    const int plen = d.path_len[vid] - pcur;
-    const bool was_stuck = (f & VF_STUCK) != 0;
-    int c = pos, moved = 0, lastdir = -1;
-    if (pre) {
-      bool go = true;
-#pragma unroll
-      for (int k = 0; k < MOVE_MAX; k++) {
-        if (go && k < m && k < plen) {
-          const int nc = cells[k + 1];
-          const uint32_t dw = dyn[k + 1].y;   // occ | stop << 8 | stuck << 16 | stat << 24
-          int occ = (int8_t)(dw & 0xFF);
-          const int stop = (int8_t)((dw >> 8) & 0xFF);
-          // the record was read before this vehicle started to move: a cell it has itself left in the meantime
-          // (a route may loop back through it) is free now - leaving clears the byte whoever else stands there
-#pragma unroll
-          for (int j = 0; j < MOVE_MAX; j++) if (j < k && cells[j] == nc) occ = 0;
-          if (occ == 1 || (stop == 1 && k != m - 1)) go = false;
-          else {
-            set_occ(d, c, 0); set_occ(d, nc, 1);
-            d.cell[c].stuck = 0; d.cell[nc].stuck = (k == 0 && was_stuck) ? 1 : 0;
-            lastdir = nc == c + d.W ? 0 : nc == c + 1 ? 1 : nc == c - d.W ? 2 : 3;
-            c = nc; moved++;
-          }
-        }
-      }
-    } else {
-      for (int k = 0; k < m; k++) {
-        if (k >= plen) break;
-        const int nd = path_dir(d.pool, off, pcur + k);
-        const int nc = step_cell(c, nd, d.W);
-        const Cell ncell = d.cell[nc];
-        if (ncell.occ == 1) break;
-        if (ncell.stop == 1 && k != m - 1) break;
-        set_occ(d, c, 0); set_occ(d, nc, 1);
-        d.cell[c].stuck = 0; d.cell[nc].stuck = (k == 0 && was_stuck) ? 1 : 0;
-        c = nc; moved++; lastdir = nd;
-      }
-    }
-    if (moved) {
-      cell_unlink(d, pos, vid);
-      cell_append(d, c, vid);
-      pos = c;
-      d.pos[vid] = c;
-      d.dir[vid] = (int8_t)lastdir;
-      if (d.stuck_ticks[vid] > 0) {
-        if (was_stuck) { atomicAdd((unsigned long long*)&d.cnt->stuck, (unsigned long long)-1LL); f &= ~VF_STUCK; }
-        d.stuck_ticks[vid] = 0;
-      }
-      d.steps[vid] += moved;
-      d.path_cur[vid] = pcur + moved;
-    }
-    f |= VF_HASPREV;
-  } else {
-    f &= ~VF_EARLY;
-    const int stop_here = pre ? (int)(int8_t)((dyn[0].y >> 8) & 0xFF) : (int)d.cell[pos].stop;
-    if ((f & VF_HASPREV) && stop_here != 1) {
-      int st = d.stuck_ticks[vid] + 1;
-      d.stuck_ticks[vid] = st;
-      if (st > P.stuck_recompute_threshold && !(f & VF_STUCK)) {
-        atomicAdd((unsigned long long*)&d.cnt->stuck, 1ULL);
-        f |= VF_STUCK;
-      }
-    }
-  }
-  if (pos == d.target[vid]) on_target_reached_dev(d, P, vid, s, pos, f, elapsed_now, key);
-  d.flags[vid] = f;
-}
-
-__device__ __forceinline__ void light_set(const Dev& d, int l, int8_t v) {  // cell.py:241-251
-  set_stop(d, d.light_cell[l], v);
-  for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1]; k++) set_stop(d, d.light_ctrl[k], v);
-}
-__device__ __forceinline__ int queue_sum(const Dev& d, const int32_t* off, const int32_t* cells, int g) {
-  int q = 0;  // compute_approach_queue (numba_utilities.py:65-72)
-  for (int k = off[g]; k < off[g + 1]; k++) q += d.occ[cells[k]];
-  return q;
-}
-__device__ __forceinline__ void apply_phase(int& cur, int& pend, int phase) {  // intersection_light_group.py:386-393
-  if (phase == cur || phase == pend) return;
-  pend = phase;
-}
-
-// IntersectionLightGroup.step (intersection_light_group.py:396-423) and _execute_phase_change (348-384)
-__device__ void group_step_dev(const Dev& d, const TsParams& P, int g) {
-  int cur = d.gs_cur[g], pend = d.gs_pend[g];
-  if (pend < 0) {
-    switch (P.light_algorithm) {
-      case TS_LIGHTS_FIXED_TIME: {
-        int t = d.gs_fttimer[g] + 1, ph = d.gs_ftphase[g];
-        if (t == 1) apply_phase(cur, pend, ph);
-        if (t >= P.green_duration) { ph = 1 - ph; t = 0; }
-        d.gs_fttimer[g] = t; d.gs_ftphase[g] = ph;
-        break;
-      }
-      case TS_LIGHTS_QUEUE_ACTUATED: {
-        int qt = d.gs_qtimer[g] + 1, gap = d.gs_gap[g], last = d.gs_last[g];
-        int ns_q = queue_sum(d, d.g_nsin_off, d.g_nsin, g), ew_q = queue_sum(d, d.g_ewin_off, d.g_ewin, g);
-        int cq = cur == 0 ? ns_q : ew_q, oq = cur == 0 ? ew_q : ns_q;
-        if (qt == 1) { last = cq; gap = 0; }
-        if (cq > last) { last = cq; gap = 0; } else gap += 1;
-        if (qt >= P.qa_min_green && (gap >= P.qa_gap || qt >= P.qa_max_green || (oq > cq && cq == 0))) {
-          apply_phase(cur, pend, 1 - cur);
-          qt = 0;
-        }
-        d.gs_qtimer[g] = qt; d.gs_gap[g] = gap; d.gs_last[g] = last;
-        break;
-      }
-      case TS_LIGHTS_PRESSURE_CONTROL:
-      case TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL: {
-        int ns_p = queue_sum(d, d.g_nsin_off, d.g_nsin, g) - queue_sum(d, d.g_nsout_off, d.g_nsout, g);
-        int ew_p = queue_sum(d, d.g_ewin_off, d.g_ewin, g) - queue_sum(d, d.g_ewout_off, d.g_ewout, g);
-        if (P.light_algorithm == TS_LIGHTS_NEIGHBOR_PRESSURE_CONTROL) {
-          const int32_t* nb = d.gs_repop[g] ? d.g_nb : d.g_nb_ctor;
-          for (int k = 0; k < 4; k++) {
-            int nd = nb[(g * 4 + k) * 2], n = nb[(g * 4 + k) * 2 + 1];
-            if (nd < 0 || n < 0) continue;
-            if (nd == 0 || nd == 2) ns_p -= d.gs_nsp[n]; else ew_p -= d.gs_ewp[n];
-          }
-        }
-        d.gs_nsp[g] = ns_p; d.gs_ewp[g] = ew_p;
-        apply_phase(cur, pend, ns_p > ew_p ? 0 : 1);
-        break;
-      }
-      case TS_LIGHTS_NEIGHBOR_GREEN_WAVE: {
-        int ns_q = queue_sum(d, d.g_nsin_off, d.g_nsin, g), ew_q = queue_sum(d, d.g_ewin_off, d.g_ewin, g);
-        bool fns = false, few = false;
-        const int32_t* nb = d.gs_repop[g] ? d.g_nb : d.g_nb_ctor;
-        for (int k = 0; k < 4; k++) {
-          int nd = nb[(g * 4 + k) * 2], n = nb[(g * 4 + k) * 2 + 1];
-          if (nd < 0 || n < 0) continue;
-          if ((nd == 0 || nd == 2) && d.gs_cur[n] == 0) fns = true;
-          if ((nd == 1 || nd == 3) && d.gs_cur[n] == 1) few = true;
-        }
-        if (fns && !few) apply_phase(cur, pend, 0);
-        else if (few && !fns) apply_phase(cur, pend, 1);
-        else apply_phase(cur, pend, ns_q > ew_q ? 0 : 1);
-        break;
-      }
-      default: break;
-    }
-  }
-  if (pend >= 0) {
-    bool done = false;
-    if (P.transition_duration_enabled && d.gs_trans[g] > 0) {
-      d.gs_trans[g] -= 1;
-      for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1]; l++) light_set(d, l, 1);
-      done = true;
-    }
-    if (!done && P.transition_clearance_enabled) {
-      bool occupied = false;  // is_intersection_occupied (285-291)
-      for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1]; k++) if (d.occ[d.g_icell[k]]) { occupied = true; break; }
-      if (occupied) {
-        for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1]; l++) light_set(d, l, 1);
-        done = true;
-      }
-    }
-    if (!done) {
-      if (P.transition_duration_enabled && d.gs_clear[g] > 0) d.gs_trans[g] = P.all_red_duration;
-      d.gs_repop[g] = 1;  // get_opposite_traffic_lights() re-ran populate_links() (303-307)
-      const int32_t *go_off = pend == 0 ? d.g_ns_off : d.g_ew_off, *go = pend == 0 ? d.g_ns : d.g_ew;
-      const int32_t *st_off = pend == 0 ? d.g_ew_off : d.g_ns_off, *st = pend == 0 ? d.g_ew : d.g_ns;
-      for (int k = go_off[g]; k < go_off[g + 1]; k++) light_set(d, go[k], 0);
-      for (int k = st_off[g]; k < st_off[g + 1]; k++) light_set(d, st[k], 1);
-      cur = pend; pend = -1;
-    }
-  }
-  d.gs_cur[g] = cur; d.gs_pend[g] = pend;
-}
-
-// An agent steps in this round iff no unresolved agent of lower rank claims a cell it reads or writes.
-__global__ void k_move_resolve(Dev d, TsParams P, int n_sched, uint32_t prefix, uint32_t rank_clock, double elapsed0,
-                               const int32_t* list, const int* list_n, int32_t* out_list, int* out_n, uint32_t rank_limit) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int s;
-  if (list) { if (t >= *list_n) return; s = list[t]; } else { s = t; if (s >= n_sched) return; }
-  if (d.resolved[s] || d.rank[s] >= rank_limit) return;
-  const int8_t kind = d.sched_kind[s];
-  const uint32_t r = d.rank[s];
-  bool safe = true;
-  if (kind == K_VEHICLE) {
-    const int vid = d.sched_ref[s];
-    const uint16_t f = d.flags[vid];
-    const int pos = d.pos[vid];
-    const bool lights = d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED;
-    // The vehicle's own cell and the cells it may enter: decode them, then load their records together (the
-    // claim words in .x-.w of the first 16 bytes, the dynamic dword right behind) - one memory round trip for
-    // both the claim test and the movement.
-    int cells[MOVE_MAX + 1];
-    uint4 claims[MOVE_MAX + 1], dyn[MOVE_MAX + 1];
-    const int m = (f & (VF_EARLY | VF_SERVICING)) ? 0 : (int)d.max_steps[vid];
-    const bool fast = m <= MOVE_MAX;
-    if (fast) {
-      const uint32_t off = d.path_off[vid];
-      const int pcur = d.path_cur[vid];
-      // the next 8 steps are at most 16 bits of the direction string: two pool words, decoded in registers
-      uint64_t bits = 0;
-      if (m > 0) {
-        const uint32_t wi = (uint32_t)pcur >> 4, nwords = ((uint32_t)d.path_len[vid] + 15u) >> 4;
-        bits = d.pool[off + wi];
-        if (wi + 1 < nwords) bits |= (uint64_t)d.pool[off + wi + 1] << 32;
-        bits >>= (pcur & 15) * 2;
-      }
-      int c = pos;
-      cells[0] = pos;
-#pragma unroll
-      for (int k = 0; k < MOVE_MAX; k++) {
-        if (k < m) c = step_cell(c, (int)((bits >> (2 * k)) & 3), d.W);
-        cells[k + 1] = c;
-      }
-#pragma unroll
-      for (int k = 0; k <= MOVE_MAX; k++) {
-        if (k <= m) {
-          const uint4* rp = reinterpret_cast<const uint4*>(&d.cell[cells[k]]);
-          claims[k] = rp[0];
-          dyn[k] = rp[1];   // .x = veh, .y = occ | stop << 8 | stuck << 16 | stat << 24
-        }
-      }
-    }
-    if (f & VF_SERVICING) {
-      // nothing on the maps is read or written
-    } else if (f & VF_EARLY) {
-      const uint4 cl = fast ? claims[0] : *reinterpret_cast<const uint4*>(&d.cell[pos]);
-      if (lights && claim_rank(cl.z, prefix) < r) safe = false;
-      if (pos == d.target[vid] && (claim_rank(cl.x, prefix) < r || claim_rank(cl.y, prefix) < r)) safe = false;
-    } else if (fast) {
-#pragma unroll
-      for (int k = 0; k <= MOVE_MAX; k++) {
-        if (k <= m && (claim_rank(claims[k].x, prefix) < r || claim_rank(claims[k].y, prefix) < r)) safe = false;
-        if (k > 0 && k <= m && lights && claim_rank(claims[k].z, prefix) < r) safe = false;
-      }
-    } else {
-      const int mm = d.max_steps[vid];
-      if (claim_rank(d.cell[pos].claim[0], prefix) < r || claim_rank(d.cell[pos].claim[1], prefix) < r) safe = false;
-      const uint32_t off = d.path_off[vid];
-      const int pcur = d.path_cur[vid];
-      int c = pos;
-      for (int k = 0; k < mm && safe; k++) {
-        c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
-        if (claim_rank(d.cell[c].claim[0], prefix) < r || claim_rank(d.cell[c].claim[1], prefix) < r) safe = false;
-        if (lights && claim_rank(d.cell[c].claim[2], prefix) < r) safe = false;
-      }
-    }
-    if (!safe) { out_list[atomicAdd(out_n, 1)] = s; return; }
-    vehicle_step_dev(d, P, vid, s, elapsed0 + (r > rank_clock ? (double)P.time_per_step_seconds : 0.0), (int)r, fast, cells, dyn);
-  } else if (kind == TS_AGENT_LIGHT_GROUP && P.light_algorithm != TS_LIGHTS_DISABLED) {
-    const int g = d.sched_ref[s];
-    for (int k = d.g_icell_off[g]; k < d.g_icell_off[g + 1] && safe; k++)
-      if (claim_rank(d.cell[d.g_icell[k]].claim[0], prefix) < r) safe = false;
-    for (int k = d.g_nsin_off[g]; k < d.g_nsin_off[g + 1] && safe; k++)
-      if (claim_rank(d.cell[d.g_nsin[k]].claim[0], prefix) < r) safe = false;
-    for (int k = d.g_ewin_off[g]; k < d.g_ewin_off[g + 1] && safe; k++)
-      if (claim_rank(d.cell[d.g_ewin[k]].claim[0], prefix) < r) safe = false;
-    if (group_reads_out(P)) {
-      for (int k = d.g_nsout_off[g]; k < d.g_nsout_off[g + 1] && safe; k++)
-        if (claim_rank(d.cell[d.g_nsout[k]].claim[0], prefix) < r) safe = false;
-      for (int k = d.g_ewout_off[g]; k < d.g_ewout_off[g + 1] && safe; k++)
-        if (claim_rank(d.cell[d.g_ewout[k]].claim[0], prefix) < r) safe = false;
-    }
-    for (int l = d.g_light_off[g]; l < d.g_light_off[g + 1] && safe; l++) {
-      int lc = d.light_cell[l];
-      if (claim_rank(d.cell[lc].claim[2], prefix) < r || claim_rank(d.cell[lc].claim[3], prefix) < r) safe = false;
-      for (int k = d.light_ctrl_off[l]; k < d.light_ctrl_off[l + 1] && safe; k++) {
-        int cc = d.light_ctrl[k];
-        if (claim_rank(d.cell[cc].claim[2], prefix) < r || claim_rank(d.cell[cc].claim[3], prefix) < r) safe = false;
-      }
-    }
-    if (safe && group_reads_neighbors(P)) {
-      for (int k = 0; k < 4 && safe; k++) {
-        for (int w = 0; w < 2; w++) {
-          int n = (w ? d.g_nb_ctor : d.g_nb)[(g * 4 + k) * 2 + 1];
-          if (n < 0) continue;
-          int ns = d.g_slot[n];
-          if (!d.resolved[ns] && d.rank[ns] < r) safe = false;  // the neighbour writes its state first
-        }
-      }
-      if (claim_rank(d.gclaim_r[g], prefix) < r) safe = false;  // a lower-ranked group still has to read mine
-    }
-    if (!safe) { out_list[atomicAdd(out_n, 1)] = s; return; }
-    group_step_dev(d, P, g);
-  }
-  d.resolved[s] = 1;
-  atomicAdd(&d.cnt->resolved, 1);
-}
-
-// ---------------------------------------------------------------------------------------------
-// stable compaction of the two ordered lists after despawns (ballot/popc within a wave, block scan in LDS)
-// ---------------------------------------------------------------------------------------------
-constexpr int CITEMS = 4;  // elements per thread
-__global__ void k_compact_count(const int32_t* active, const int8_t* kind, int n, int which, int* block_counts) {
-  __shared__ int wsum[BLK / 64];
-  int base = blockIdx.x * BLK * CITEMS;
-  int c = 0;
-  for (int j = 0; j < CITEMS; j++) {
-    int i = base + j * BLK + threadIdx.x;
-    if (i < n) c += which == 0 ? (active[i] >= 0) : (kind[i] != K_DEAD);
-  }
-  for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < BLK / 64; w++) t += wsum[w]; block_counts[blockIdx.x] = t; }
-}
-__global__ void k_scan_blocks(int* block_counts, int nb, int* total) {  // single block, exclusive scan in place
-  __shared__ int carry;
-  __shared__ int buf[1024];
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nb; base += 1024) {
-    int i = base + threadIdx.x;
-    int v = i < nb ? block_counts[i] : 0;
-    buf[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      int t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
-      __syncthreads();
-      buf[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < nb) block_counts[i] = carry + buf[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += buf[1023];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *total = carry;
-}
-// Rows are visited j-major inside a block, so the block's output order is preserved by scanning each
-// j-slab in turn (slab = BLK consecutive elements).
-__global__ void k_compact_scatter(Dev d, int n, int which, const int* block_off, int32_t* out_a, int8_t* out_kind,
-                                  int32_t* out_ref) {
-  __shared__ int wcnt[BLK / 64];
-  __shared__ int running;
-  if (threadIdx.x == 0) running = block_off[blockIdx.x];
-  __syncthreads();
-  int base = blockIdx.x * BLK * CITEMS;
-  for (int j = 0; j < CITEMS; j++) {
-    int i = base + j * BLK + threadIdx.x;
-    bool keep = false;
-    if (i < n) keep = which == 0 ? (d.active[i] >= 0) : (d.sched_kind[i] != K_DEAD);
-    unsigned long long m = __ballot(keep);
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int before = __popcll(m & ((1ULL << lane) - 1));
-    if (lane == 0) wcnt[w] = __popcll(m);
-    __syncthreads();
-    int woff = 0;
-    for (int q = 0; q < w; q++) woff += wcnt[q];
-    int dst = running + woff + before;
-    if (keep) {
-      if (which == 0) {
-        int vid = d.active[i];
-        out_a[dst] = vid;
-        d.active_idx[vid] = dst;
-      } else {
-        int8_t k = d.sched_kind[i];
-        int ref = d.sched_ref[i];
-        out_kind[dst] = k; out_ref[dst] = ref;
-        // which table remembers this agent's slot (a plain select: the if / else-if chain with the two-kind arm
-        // was miscompiled for gfx950 by ROCm 7.2's hipcc at -O3, leaving the K_RAIN lane's base pointer undefined)
-        int32_t* tab = nullptr;
-        switch (k) {
-          case K_VEHICLE: tab = d.sched_slot; break;
-          case TS_AGENT_LIGHT_GROUP: tab = d.g_slot; break;
-          case TS_AGENT_RAIN_MANAGER: tab = d.hslot; break;
-          case K_RAIN: tab = d.hslot; break;
-          case TS_AGENT_CITY_BLOCK: tab = d.bslot; break;
-          default: break;
-        }
-        if (tab) tab[ref] = dst;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < BLK / 64; q++) t += wcnt[q]; running += t; }
-    __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// spawn, read-back and density kernels
-// ---------------------------------------------------------------------------------------------
-struct SpawnArgs {
-  const int32_t *start, *goal, *pop, *plen;
-  const uint32_t* poff;
-  const uint8_t* serial;  // 1 = start cell shared inside the batch -> placed by the serial kernel
-};
-__global__ void k_spawn(Dev d, TsParams P, SpawnArgs a, int n, int vid0, int active0, int sched0, double elapsed,
-                        int* overflow, int* n_overflow) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int vid = vid0 + i;
-  int pos = a.start[i];
-  d.pos[vid] = pos; d.target[vid] = a.goal[i];
-  d.path_off[vid] = a.poff[i]; d.path_len[vid] = a.plen[i]; d.path_cur[vid] = 0;
-  d.stuck_ticks[vid] = 0; d.cooldown[vid] = P.pathfinding_cooldown; d.stranded_left[vid] = 0; d.steps[vid] = 0;
-  d.over_dur[vid] = -1; d.det_dur[vid] = -1; d.next_in_cell[vid] = -1;
-  d.base_speed[vid] = 0; d.cur_speed[vid] = 0; d.max_steps[vid] = 0; d.dir[vid] = -1; d.pop[vid] = (int8_t)a.pop[i];
-  d.flags[vid] = VF_ALIVE; d.depart[vid] = P.enable_traffic ? elapsed : 0.0;
-  d.ev[vid] = 0; d.st_before[vid] = 0; d.st_after[vid] = 0; d.tier_hint[vid] = 0;
-  for (int k = 0; k < 4; k++) { d.ax_len[k][vid] = 0; d.ax_off[k][vid] = 0; d.ax_start[k][vid] = pos; }
-  d.active[active0 + i] = vid; d.active_idx[vid] = active0 + i;
-  d.sched_kind[sched0 + i] = K_VEHICLE; d.sched_ref[sched0 + i] = vid; d.sched_slot[vid] = sched0 + i;
-  set_occ(d, pos, 1); d.cell[pos].stuck = 0;  // place_vehicle (city_model.py:1897-1918)
-  if (a.serial[i] || atomicCAS(&d.cell[pos].veh, -1, vid) != -1) overflow[atomicAdd(n_overflow, 1)] = vid;
-}
-__global__ void k_spawn_serial(Dev d, int* overflow, int n_overflow) {  // cells holding several vehicles: list order = spawn order
-  if (threadIdx.x || blockIdx.x) return;
-  for (int a = 1; a < n_overflow; a++) {  // insertion sort by vehicle id (tiny)
-    int v = overflow[a], b = a - 1;
-    while (b >= 0 && overflow[b] > v) { overflow[b + 1] = overflow[b]; b--; }
-    overflow[b + 1] = v;
-  }
-  for (int a = 0; a < n_overflow; a++) cell_append(d, d.pos[overflow[a]], overflow[a]);
-}
-
-__global__ void k_rows(Dev d, int n_active, const uint32_t* crc_table, int32_t* rows) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_active) return;
-  int vid = d.active[i];
-  int32_t* r = rows + (size_t)i * TS_V_NFIELDS;
-  int pos = d.pos[vid];
-  r[TS_V_SPAWN_IDX] = vid; r[TS_V_X] = pos % d.W; r[TS_V_Y] = pos / d.W;
-  r[TS_V_BASE_SPEED] = d.base_speed[vid]; r[TS_V_CURRENT_SPEED] = d.cur_speed[vid]; r[TS_V_MAX_STEPS] = d.max_steps[vid];
-  r[TS_V_DIRECTION] = d.dir[vid]; r[TS_V_STUCK_TICKS] = d.stuck_ticks[vid]; r[TS_V_COOLDOWN] = d.cooldown[vid];
-  r[TS_V_FLAGS] = d.flags[vid] & 0x1FF; r[TS_V_STRANDED_LEFT] = d.stranded_left[vid];
-  r[TS_V_STEPS_TRAVELED] = d.steps[vid];
-  int pcur = d.path_cur[vid], plen = d.path_len[vid] - pcur;
-  r[TS_V_PATH_LEN] = plen;
-  uint32_t crc = 0;
-  if (plen > 0) {
-    crc = 0xFFFFFFFFu;
-    int c = pos;
-    uint32_t off = d.path_off[vid];
-    for (int k = 0; k < plen; k++) {
-      c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
-      int32_t xy[2] = {c % d.W, c / d.W};
-      const uint8_t* p = (const uint8_t*)xy;
-      for (int b = 0; b < 8; b++) crc = crc_table[(crc ^ p[b]) & 0xff] ^ (crc >> 8);
-    }
-    crc ^= 0xFFFFFFFFu;
-  }
-  r[TS_V_PATH_CRC] = (int32_t)crc;
-  r[TS_V_OVERTAKE_DUR] = d.over_dur[vid]; r[TS_V_DETOUR_DUR] = d.det_dur[vid];
-}
-__global__ void k_meta_rows(Dev d, int n_active, int32_t* rows) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_active) return;
-  const int vid = d.active[i];
-  int32_t* r = rows + (size_t)i * TS_M_NFIELDS;
-  const int tgt = d.target[vid];
-  const uint16_t f = d.flags[vid];
-  r[TS_M_SPAWN_IDX] = vid; r[TS_M_POPULATION] = d.pop[vid]; r[TS_M_TARGET_X] = tgt % d.W; r[TS_M_TARGET_Y] = tgt / d.W;
-  r[TS_M_VEHICLE_TYPE] = 0;   // the fleet (food / waste) is host state: filled in by ts_download_vehicle_meta
-  r[TS_M_SERVICE_PHASE] = !(f & VF_SVC) ? -1 : (f & VF_TOBLOCK) ? 0 : (f & VF_SERVICING) ? 1 : 2;
-}
-
-__global__ void k_path_cells(Dev d, int vid, int32_t* xy) {
-  if (threadIdx.x || blockIdx.x) return;
-  int pcur = d.path_cur[vid], plen = d.path_len[vid] - pcur, c = d.pos[vid];
-  uint32_t off = d.path_off[vid];
-  for (int k = 0; k < plen; k++) {
-    c = step_cell(c, path_dir(d.pool, off, pcur + k), d.W);
-    xy[2 * k] = c % d.W; xy[2 * k + 1] = c / d.W;
-  }
-}
-__global__ void k_group_rows(Dev d, int32_t* rows) {
-  int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= d.G) return;
-  int32_t* r = rows + (size_t)g * TS_G_NFIELDS;
-  r[TS_G_CURRENT_PHASE] = d.gs_cur[g]; r[TS_G_PENDING_PHASE] = d.gs_pend[g]; r[TS_G_QUEUE_TIMER] = d.gs_qtimer[g];
-  r[TS_G_GAP_TIMER] = d.gs_gap[g]; r[TS_G_LAST_ARRIVAL] = d.gs_last[g]; r[TS_G_FIXED_TIME_TIMER] = d.gs_fttimer[g];
-  r[TS_G_FT_PHASE] = d.gs_ftphase[g]; r[TS_G_NS_PRESSURE] = d.gs_nsp[g]; r[TS_G_EW_PRESSURE] = d.gs_ewp[g];
-}
-
-// _update_density_map (city_model.py:1764-1778): scipy.ndimage.uniform_filter on float32 = two 1-D passes
-// with double accumulators and a float32 intermediate; `* 441` and the division in float32.
-__global__ void k_density_pass0(const int8_t* occ, const int8_t* road, int W, int H, int r, float* t_occ, float* t_road) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= W * H) return;
-  int x = i % W, y = i / W;
-  int y0 = max(0, y - r), y1 = min(H - 1, y + r);
-  int c0 = 0, c1 = 0;
-  for (int yy = y0; yy <= y1; yy++) { c0 += occ[yy * W + x]; c1 += road[yy * W + x]; }
-  const double size = (double)(2 * r + 1);
-  t_occ[i] = (float)((double)c0 / size);
-  t_road[i] = (float)((double)c1 / size);
-}
-__global__ void k_density_pass1(const float* t_occ, const float* t_road, int W, int H, int r, float* density) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= W * H) return;
-  int x = i % W, y = i / W;
-  int x0 = max(0, x - r), x1 = min(W - 1, x + r);
-  double s0 = 0.0, s1 = 0.0;
-  for (int xx = x0; xx <= x1; xx++) { s0 += (double)t_occ[y * W + xx]; s1 += (double)t_road[y * W + xx]; }
-  const double size = (double)(2 * r + 1);
-  const float area = (float)((2 * r + 1) * (2 * r + 1));
-  float v0 = (float)(s0 / size) * area, v1 = (float)(s1 / size) * area;
-  density[i] = v1 > 0.f ? __fdiv_rn(v0, v1) : 0.f;
-}
-
-// rain_map = union of the clouds' discs as RainManager.step saw them (rain.py:156-184): a cell is covered by a
-// cloud when (x - cx)^2 + (y - cy)^2 <= r^2 for the cloud's integer centre at its last step
-struct RainDiscs { int n; int cx[16], cy[16], r[16]; };
-// RainManager.step (rain.py:156-184): the cells that rained at its previous step are cleared, the cells under the
-// clouds it sees now are set; everything else (a host may have written the map) stays as it is
-__global__ void k_rain_map(int8_t* rain, int W, int H, RainDiscs prev, RainDiscs D) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= W * H) return;
-  const int x = i % W, y = i / W;
-  bool was = false, is = false;
-  for (int k = 0; k < prev.n; k++) {
-    const int dx = x - prev.cx[k], dy = y - prev.cy[k];
-    if (dx * dx + dy * dy <= prev.r[k] * prev.r[k]) was = true;
-  }
-  for (int k = 0; k < D.n; k++) {
-    const int dx = x - D.cx[k], dy = y - D.cy[k];
-    if (dx * dx + dy * dy <= D.r[k] * D.r[k]) is = true;
-  }
-  if (is) rain[i] = 1;
-  else if (was) rain[i] = 0;
-}
-
-// rank[slot] = position of the slot in the shuffled key order
-// cell records <-> byte planes
-__global__ void k_cells_init(Cell* cell, int n, const uint8_t* allowed, const int8_t* is_road, const int8_t* road_type,
-                             const int8_t* inter) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  Cell x;
-  x.claim[0] = x.claim[1] = x.claim[2] = x.claim[3] = 0xFFFFFFFFu;
-  x.veh = -1; x.occ = 0; x.stop = 0; x.stuck = 0;
-  x.stat = (uint8_t)((allowed[c] & 15) | ((is_road[c] == 1) << 4) | ((inter[c] == 1) << 5) | ((road_type[c] & 3) << 6));
-  x.pad_[0] = x.pad_[1] = 0;
-  cell[c] = x;
-}
-__global__ void k_claims_reset(Cell* cell, int n) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  cell[c].claim[0] = cell[c].claim[1] = cell[c].claim[2] = cell[c].claim[3] = 0xFFFFFFFFu;
-}
-__global__ void k_plane_to_cells(Cell* cell, int n, const int8_t* plane, int which) {   // which: 0 occ, 1 stop
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  if (which == 0) cell[c].occ = plane[c]; else cell[c].stop = plane[c];
-}
-__global__ void k_cells_to_plane(const Cell* cell, int n, int8_t* plane) {   // stuck_map
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  plane[c] = cell[c].stuck;
-}
-
-// on_target_reached inside step_decide for the vehicles that stay (AR_DECIDE records): the flag changes other
-// deciders must not see half-way are applied once the decide kernels are done
-__global__ void k_decide_arrive(Dev d, int n_rec) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_rec || d.arr[3 * k + 2] != AR_DECIDE) return;
-  const int vid = d.arr[3 * k + 1];
-  uint16_t f = d.flags[vid];
-  if (!(f & VF_PARKED)) { f |= VF_PARKED; atomicAdd((unsigned long long*)&d.cnt->parked, 1ULL); }
-  if (f & VF_TOBLOCK) f = (f & ~VF_TOBLOCK) | VF_SERVICING;
-  d.flags[vid] = f;
-}
-// (schedule slot, rank) of CityBlocks (which = 0, ids = block index) or vehicles (which = 1, ids = vehicle id)
-__global__ void k_gather_ranks(Dev d, const int32_t* ids, int n, int which, int32_t* out) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const int slot = which == 0 ? d.bslot[ids[k]] : d.sched_slot[ids[k]];
-  out[2 * k] = slot; out[2 * k + 1] = (int)d.rank[slot];
-}
-// ServiceVehicleAgent._finish_service, device part: _unpark, new target, phase (vehicle_service.py:106-141);
-// _compute_path's cooldown reset (vehicle_base.py:147)
-__global__ void k_svc_finish(Dev d, TsParams P, int vid, int target, int to_block) {
-  if (threadIdx.x || blockIdx.x) return;
-  uint16_t f = d.flags[vid];
-  if (f & VF_PARKED) { f &= ~VF_PARKED; atomicAdd((unsigned long long*)&d.cnt->parked, (unsigned long long)-1LL); }
-  f &= ~(VF_SERVICING | VF_TOBLOCK);
-  if (to_block) f |= VF_TOBLOCK; else f &= ~VF_KEEP;   // remove_on_arrival = True on the way out
-  d.flags[vid] = f;
-  d.target[vid] = target;
-  d.cooldown[vid] = P.pathfinding_cooldown;
-}
-__global__ void k_flags_or(Dev d, int vid, int bits) {
-  if (threadIdx.x || blockIdx.x) return;
-  d.flags[vid] |= (uint16_t)bits;
-}
-
-__global__ void k_rank_invert(const uint32_t* perm, uint32_t* rank, int n) {
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < n) rank[perm[q]] = (uint32_t)q;
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// decide-phase RNG bookkeeping on the device.  Per vehicle the draw byte F says: 2 words for the malfunction
-// draw, 2 for a sideswipe draw, then a rejection-sampled speed roll.  The fixed parts are a prefix sum
-// (pass 1, here); only the rolls form a serial chain (pass 2, host, ~0.45 chain steps per vehicle through the
-// producer's take table); pass 3 (k_rng_apply) turns stream positions into decisions for every vehicle.
-// ---------------------------------------------------------------------------------------------
-constexpr int RS_ITEMS = 4;
-__device__ __forceinline__ uint2 rng_item(uint8_t f) {
-  return make_uint2(2u * (f & 1u) + 2u * ((f >> 1) & 1u), (f >> 2) & 1u);  // (fixed words, is a roller)
-}
-__global__ void k_rng_blocksum(const uint8_t* F, int start, int n, uint2* block_sums) {
-  __shared__ uint2 wsum[BLK / 64];
-  const int base = blockIdx.x * BLK * RS_ITEMS + threadIdx.x * RS_ITEMS;
-  uint2 a = make_uint2(0, 0);
-  for (int j = 0; j < RS_ITEMS; j++) {
-    int i = base + j;
-    if (i < n) { uint2 v = rng_item(F[start + i]); a.x += v.x; a.y += v.y; }
-  }
-  for (int o = 32; o; o >>= 1) { a.x += __shfl_down(a.x, o); a.y += __shfl_down(a.y, o); }
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint2 t = make_uint2(0, 0);
-    for (int w = 0; w < BLK / 64; w++) { t.x += wsum[w].x; t.y += wsum[w].y; }
-    block_sums[blockIdx.x] = t;
-  }
-}
-__global__ void k_rng_scanblocks(uint2* block_sums, int nb, unsigned int* total) {  // single block, exclusive, in place
-  __shared__ uint2 carry;
-  __shared__ uint2 buf[1024];
-  if (threadIdx.x == 0) carry = make_uint2(0, 0);
-  __syncthreads();
-  for (int base = 0; base < nb; base += 1024) {
-    int i = base + threadIdx.x;
-    uint2 v = i < nb ? block_sums[i] : make_uint2(0, 0);
-    buf[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      uint2 t = threadIdx.x >= o ? buf[threadIdx.x - o] : make_uint2(0, 0);
-      __syncthreads();
-      buf[threadIdx.x].x += t.x; buf[threadIdx.x].y += t.y;
-      __syncthreads();
-    }
-    if (i < nb) block_sums[i] = make_uint2(carry.x + buf[threadIdx.x].x - v.x, carry.y + buf[threadIdx.x].y - v.y);
-    __syncthreads();
-    if (threadIdx.x == 1023) { carry.x += buf[1023].x; carry.y += buf[1023].y; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { total[0] = carry.x; total[1] = carry.y; }
-}
-__global__ void k_rng_final(Dev d, int start, int n, const uint2* block_off) {
-  __shared__ uint2 tsum[BLK];
-  const int base = blockIdx.x * BLK * RS_ITEMS + threadIdx.x * RS_ITEMS;
-  uint2 item[RS_ITEMS];
-  uint2 a = make_uint2(0, 0);
-  for (int j = 0; j < RS_ITEMS; j++) {
-    int i = base + j;
-    item[j] = i < n ? rng_item(d.F[start + i]) : make_uint2(0, 0);
-    a.x += item[j].x; a.y += item[j].y;
-  }
-  tsum[threadIdx.x] = a;
-  __syncthreads();
-  for (int o = 1; o < BLK; o <<= 1) {  // inclusive scan of the per-thread sums
-    uint2 t = threadIdx.x >= o ? tsum[threadIdx.x - o] : make_uint2(0, 0);
-    __syncthreads();
-    tsum[threadIdx.x].x += t.x; tsum[threadIdx.x].y += t.y;
-    __syncthreads();
-  }
-  uint2 run = block_off[blockIdx.x];
-  run.x += tsum[threadIdx.x].x - a.x; run.y += tsum[threadIdx.x].y - a.y;
-  for (int j = 0; j < RS_ITEMS; j++) {
-    int i = base + j;
-    if (i >= n) break;
-    d.Cx[start + i] = run.x;          // fixed words consumed by the vehicles before this one (in this pass)
-    d.rollrank[start + i] = run.y;    // rolls before this one
-    if (item[j].y) d.rollD[run.y] = run.x + item[j].x;  // where its roll starts, apart from earlier rolls' lengths
-    run.x += item[j].x; run.y += item[j].y;
-  }
-}
-// take table for the host chain: out[i] = words a speed roll starting at stream position base + i consumes
-// (1 + number of rejected words from there on; 0 = more than 64, the host counts those by hand)
-__global__ void k_rng_take(const uint32_t* words, unsigned long long base, int n, uint32_t span, int rshift, uint8_t* out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned long long p = base + (unsigned long long)i;
-  int t = 1;
-  while (t <= 64 && (words[(p + t - 1) & WORDS_MASK] >> rshift) >= span) t++;
-  out[i] = t <= 64 ? (uint8_t)t : (uint8_t)0;
-}
-
-// pass 3: every vehicle of [start, start + n) reads its words.  base = stream position of vehicle `start`.
-__global__ void k_rng_apply(Dev d, int start, int n, unsigned long long base, unsigned long long t_malf,
-                            unsigned long long t_swipe, uint32_t span, int rshift, int min_speed) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const int i = start + t;
-  const uint32_t f = d.F[i];
-  const uint32_t rr = d.rollrank[i];
-  const uint32_t tb = d.Tcum[rr];
-  unsigned long long w = base + d.Cx[i] + tb;
-  uint8_t roll = 0;
-  bool fired = false;
-  if (f & F_DRAW_MALF) {
-    const unsigned long long k = ((unsigned long long)(d.words[w & WORDS_MASK] >> 5) << 26) |
-                                 (unsigned long long)(d.words[(w + 1) & WORDS_MASK] >> 6);
-    w += 2;
-    if (k < t_malf) { atomicMin(&d.cnt->rng_event, (unsigned int)i * 2u); fired = true; }
-  }
-  if (!fired && (f & F_DRAW_SWIPE)) {
-    const unsigned long long k = ((unsigned long long)(d.words[w & WORDS_MASK] >> 5) << 26) |
-                                 (unsigned long long)(d.words[(w + 1) & WORDS_MASK] >> 6);
-    w += 2;
-    if (k < t_swipe) { atomicMin(&d.cnt->rng_event, (unsigned int)i * 2u + 1u); fired = true; }
-  } else if (f & F_DRAW_SWIPE) w += 2;
-  if (!fired && (f & F_DRAW_SPEED)) {
-    const uint32_t tk = d.Tcum[rr + 1] - tb;
-    roll = (uint8_t)(min_speed + (int)(d.words[(w + tk - 1) & WORDS_MASK] >> rshift));
-  }
-  d.R[i] = roll;
-}
-
-template <typename T>
-__global__ void k_fill(T* p, T v, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-
-inline int nblk(long long n, int per = BLK) { return (int)((n + per - 1) / per); }
-
-}  // namespace
-
-// =============================================================================================
-// host side
-// =============================================================================================
-struct ts_engine {
-  TsParams P;
-  Dev d;
-  int W = 0, H = 0, N = 0;
-  hipStream_t stream = nullptr;
-  std::string err;
-  // capacities
-  int cap_v = 0, cap_sched = 0;
-  size_t pool_cap = 0, pool_used = 0;
-  int n_vehicles_total = 0;  // vehicle ids handed out
-  int n_active = 0, n_sched = 0;
-  int n_sched_vehicles = 0;
-  int clock_slot = -1;
-  bool mixed_order = false;  // a non-vehicle agent was scheduled after a vehicle
-  int groups_scheduled = 0;
-  bool lights_set = false;
-  // double buffers for compaction
-  int32_t* active_alt = nullptr;
-  int8_t* kind_alt = nullptr;
-  int32_t* ref_alt = nullptr;
-  int* block_counts = nullptr;
-  int cap_blocks = 0;
-  int* d_total = nullptr;
-  uint32_t* d_crc = nullptr;
-  int* d_overflow = nullptr;
-  int cap_overflow = 0;
-  // pinned host staging
-  uint8_t *hF = nullptr, *hR = nullptr;
-  uint32_t* hrank = nullptr;
-  DevCnt* hcnt = nullptr;
-  int* hint = nullptr;
-  int cap_host = 0;
-  // RNG streams (host)
-  MTPipe rng_global, rng_sched;   // word streams pre-generated by producer threads
-  uint32_t* d_perm = nullptr;     // shuffled key order (perm[q] = slot stepping at time q)
-  uint32_t rank_clock_host = 0xFFFFFFFFu;
-  uint32_t epoch = 0;
-  TsCounters C;
-  std::vector<uint32_t> perm, shuffle_j;
-  int32_t* pend_list[2] = {nullptr, nullptr};
-  // RainManager / RainAgent (host side, rain.py): clouds are host agents with a schedule entry of their own
-  struct Rain { double x, y, dx, dy; int radius; bool stepped = false; bool alive = true; int cx = 0, cy = 0; };
-  std::vector<Rain> rains_all;   // indexed by host-agent id - 1 (id 0 is the manager)
-  std::vector<int> rains;        // city_model.rains: ids of live clouds in list order
-  bool rain_manager = false;
-  RainDiscs prev_discs{};         // what the manager saw at its previous step (RainManager._prev_raining)
-  int rain_counter = 0, rain_cooldown_left = 0;
-  int n_host_agents = 0;         // manager + clouds ever created (hslot entries)
-  int cap_hslot = 0;
-  // DynamicTrafficAgent (host side): trip schedule + mid-tick spawning behind the clock agent's schedule slot
-  struct Trip { int origin, dest; double depart; int kind; };
-  struct Generator {
-    bool armed = false;
-    TsTrafficTables T;
-    std::vector<int> blk_type;
-    std::vector<std::vector<int>> blk_entr;
-    std::vector<int> hw_in, hw_out;
-    std::vector<Trip> pending;
-    int current_day = 0;
-  } gen;
-  // CityBlock food / waste and ServiceVehicleAgent loads: host state, advanced in rank order next to the device's
-  // move phase (city_block.py, vehicle_service.py)
-  struct Block {
-    int cells = 0;
-    bool needs_food = false, produces_waste = false;
-    double max_food = 0, max_waste = 0, food = 0, waste = 0, food_rate = 0, waste_rate = 0, food_rem = 0, waste_rem = 0;
-    int ticks_since_food = 0, ticks_since_waste = 0;
-    std::vector<int> service_cells;
-  };
-  std::vector<Block> blocks;
-  int blocks_scheduled = 0, cap_bslot = 0;
-  struct SvcVeh {
-    int vid, type, id, block;     // type: TS_TRIP_SERVICE_FOOD / _WASTE; id: index into the fleet's id pool
-    double load, max_load;
-    int phase;                    // 0 to_block, 1 servicing, 2 to_exit
-    int ticks;                    // service_ticks
-    int pos;                      // where it parked (valid while servicing)
-    int target;
-  };
-  std::vector<SvcVeh> svc;                      // live service vehicles
-  std::unordered_map<int, int> parked_cells;    // cell -> parked vehicles on it (only service vehicles ever park)
-  std::vector<char> sv_live;                    // ids in the scheduler: [food ids..., waste ids...]
-  int32_t *d_ids = nullptr, *d_sr = nullptr;    // k_gather_ranks staging
-  int cap_ids = 0;
-  int fatal = 0;                                // an exception the reference would have raised inside model.step()
-  // device-side RNG bookkeeping
-  uint32_t* h_words = nullptr;        // pinned storage of the global stream's tempered-word ring
-  uint64_t words_uploaded = 0;        // absolute word index up to which d.words mirrors it
-  hipStream_t copy_stream = nullptr;
-  hipEvent_t words_ev = nullptr;
-  uint2* rng_blocks = nullptr;
-  int cap_rng_blocks = 0;
-  uint32_t *h_rollD = nullptr, *h_Tcum = nullptr;
-  int roll_guess = 0;
-  uint32_t* bfs_visited = nullptr;   // k_reach_strict scratch: per wave a visited bitmap and a queue
-  int32_t* bfs_queue = nullptr;
-  int bfs_slots = 0;
-  uint8_t *d_take = nullptr, *h_take = nullptr;   // take table of the stream range the next pass will walk
-  size_t cap_take = 0;
-  uint64_t take_guess = 0;
-  // the table for the NEXT tick is built right after this tick's decide phase (copy stream, overlapping the move
-  // phase): [take_base, take_base + take_n) in absolute stream positions, ready once take_ev has fired
-  uint64_t take_base = 0;
-  size_t take_n = 0;
-  hipEvent_t take_ev = nullptr;
-  std::thread sh_thread, sh2_thread;
-  std::atomic<int> sh_progress{0};   // draws extracted so far (shuffle pipeline)
-  unsigned sh_gen = 0;
-  int sh_err = 0;
-  int device = 0;
-  hipStream_t perm_stream = nullptr;
-  hipEvent_t perm_ev = nullptr;
-  std::mutex sh_mu;
-  std::condition_variable sh_cv;
-  bool sh_done = true, sh_quit = false;
-  int sh_n = 0;
-  std::vector<void*> allocs;
-  // per-kernel HIP-event timing (ts_profile_*)
-  // replanning: work lists, scratch tiers, density state, host-side _path_cache
-  int32_t* replan_list[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // see run_replans
-  int cap_replan = 0;
-  static constexpr int N_TIERS = 4;
-  ATier tier[N_TIERS];
-  bool tier_ready[N_TIERS] = {false, false, false, false};
-  bool density_valid = false;
-  float *dens_t0 = nullptr, *dens_t1 = nullptr;
-  int32_t* d_status = nullptr;
-  struct CachedPath { std::vector<uint32_t> words; int len; };
-  std::unordered_map<uint64_t, CachedPath> path_cache;
-  bool prof = false;
-  std::vector<hipEvent_t> ev_pool;
-  struct ProfRec { int id; int e0, e1; long long items; };
-  std::vector<ProfRec> prof_pending;
-  size_t ev_used = 0;
-  double prof_ms[24] = {0};
-  long long prof_launches[24] = {0}, prof_items[24] = {0};
-  double shuffle_ms = 0;
-};
-
-static int add_vehicle_planned(ts_handle e, int start, int goal, int pop_type);  // defined with the C-ABI entries
-static int plan_vehicle(ts_handle e, int vid, int start, int goal);
-
-namespace {
-
-typedef ts_engine E;
-
-enum { PK_DECIDE_PRE = 0, PK_DECIDE_MAIN, PK_MOVE_CLAIM, PK_MOVE_RESOLVE, PK_COMPACT, PK_EVENT, PK_REPLAN, PK_DENSITY, PK_RNG, PK_REACH, PH_SCAN, PH_SHUFFLE, PH_SHUFFLE_WAIT, PH_DECIDE_WALL, PH_MOVE_WALL, PH_WAIT1, PH_WORDS, PH_WAIT3, PH_NEED, PK_COUNT };
-const char* PK_NAMES[PK_COUNT] = {"k_decide_pre", "k_decide_main", "k_move_claim", "k_move_resolve",
-                                  "k_compact", "k_apply_event", "k_decide_replan", "k_density", "k_rng", "k_reach_strict",
-                                  "host_rng_scan", "host_shuffle", "host_shuffle_wait", "host_decide_wall", "host_move_wall",
-                                  "host_wait_pass1", "host_words_upload", "host_wait_pass3", "host_words_need"};
-
-int prof_begin(E* e, int id, long long items) {
-  if (!e->prof) return -1;
-  if (e->ev_used + 2 > e->ev_pool.size()) {
-    for (int k = 0; k < 64; k++) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return -1; e->ev_pool.push_back(ev); }
-  }
-  int a = (int)e->ev_used, b = a + 1;
-  e->ev_used += 2;
-  (void)hipEventRecord(e->ev_pool[a], e->stream);
-  e->prof_pending.push_back({id, a, b, items});
-  return b;
-}
-inline void prof_end(E* e, int tok) { if (tok >= 0) (void)hipEventRecord(e->ev_pool[tok], e->stream); }
-void prof_collect(E* e) {  // call after a stream synchronize
-  for (auto& r : e->prof_pending) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e->ev_pool[r.e0], e->ev_pool[r.e1]) == hipSuccess) {
-      e->prof_ms[r.id] += ms; e->prof_launches[r.id]++; e->prof_items[r.id] += r.items;
-    }
-  }
-  e->prof_pending.clear();
-  e->ev_used = 0;
-}
-#define LAUNCH(e, id, items, kernel, grid, block, ...)                                   \
-  do {                                                                                   \
-    int _tok = prof_begin((e), (id), (items));                                           \
-    hipLaunchKernelGGL(kernel, grid, block, 0, (e)->stream, __VA_ARGS__);                \
-    prof_end((e), _tok);                                                                 \
-  } while (0)
-
-int fail(E* e, int code, const std::string& msg) {
-  if (e) e->err = msg;
-  return code;
-}
-#define HIPOK(expr)                                                                                   \
-  do {                                                                                                \
-    hipError_t _e = (expr);                                                                           \
-    if (_e != hipSuccess)                                                                             \
-      return fail(e, TS_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));                  \
-  } while (0)
-
-template <typename T>
-hipError_t dalloc(E* e, T** p, size_t n) {
-  hipError_t r = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
-  if (r == hipSuccess) e->allocs.push_back((void*)*p);
-  return r;
-}
-void dfree(E* e, void* p) {
-  if (!p) return;
-  auto it = std::find(e->allocs.begin(), e->allocs.end(), p);
-  if (it != e->allocs.end()) e->allocs.erase(it);
-  (void)hipFree(p);
-}
-// grow a device array, preserving `keep` elements
-template <typename T>
-int regrow(E* e, T** p, size_t keep, size_t n) {
-  T* q = nullptr;
-  HIPOK(dalloc(e, &q, n));
-  if (*p && keep) HIPOK(hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, e->stream));
-  HIPOK(hipStreamSynchronize(e->stream));
-  dfree(e, *p);
-  *p = q;
-  return TS_OK;
-}
-
-int ensure_vehicle_capacity(E* e, int need_v, int need_sched) {
-  if (need_v > e->cap_v) {
-    int nc = std::max(need_v, e->cap_v * 2 + 1024);
-    Dev& d = e->d;
-    size_t k = e->n_vehicles_total;
-#define RG(field) { int rc = regrow(e, &d.field, k, (size_t)nc); if (rc) return rc; }
-    RG(pos) RG(target) RG(path_len) RG(path_cur) RG(stuck_ticks) RG(cooldown) RG(stranded_left) RG(steps) RG(over_dur)
-    RG(det_dur) RG(next_in_cell) RG(active_idx) RG(sched_slot) RG(path_off) RG(base_speed) RG(cur_speed) RG(max_steps)
-    RG(dir) RG(pop) RG(flags) RG(depart) RG(ev) RG(st_before) RG(st_after) RG(ev_idx) RG(reach) RG(tier_hint)
-    for (int k = 0; k < 4; k++) { RG(ax_start[k]) RG(ax_off[k]) RG(ax_len[k]) }
-#undef RG
-    { int rc = regrow(e, &e->replan_list[0], 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &e->replan_list[1], 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &e->replan_list[2], 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &e->replan_list[3], 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &e->replan_list[4], 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &e->replan_list[5], 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &d.active, (size_t)e->n_active, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &e->active_alt, 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &d.F, 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &d.R, 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &d.cand, 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &d.Cx, 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &d.rollrank, 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &d.rollD, 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &d.Tcum, 0, (size_t)nc + 1); if (rc) return rc; }
-    {
-      int nbk = nblk(nc, BLK * RS_ITEMS) + 1;
-      int rc = regrow(e, &e->rng_blocks, 0, (size_t)nbk); if (rc) return rc;
-      e->cap_rng_blocks = nbk;
-    }
-    if (e->h_rollD) (void)hipHostFree(e->h_rollD);
-    if (e->h_Tcum) (void)hipHostFree(e->h_Tcum);
-    HIPOK(hipHostMalloc((void**)&e->h_rollD, (size_t)nc * 4));
-    HIPOK(hipHostMalloc((void**)&e->h_Tcum, ((size_t)nc + 1) * 4));
-    e->cap_v = nc;
-  }
-  if (need_sched > e->cap_sched) {
-    int nc = std::max(need_sched, e->cap_sched * 2 + 1024);
-    Dev& d = e->d;
-    { int rc = regrow(e, &d.sched_kind, (size_t)e->n_sched, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &d.sched_ref, (size_t)e->n_sched, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &d.rank, 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &e->d_perm, 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &e->pend_list[0], 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &e->pend_list[1], 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &d.resolved, 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &e->kind_alt, 0, (size_t)nc); if (rc) return rc; }
-    { int rc = regrow(e, &e->ref_alt, 0, (size_t)nc); if (rc) return rc; }
-    e->cap_sched = nc;
-  }
-  int need_host = std::max(need_v, need_sched);
-  if (need_host > e->cap_host) {
-    int nc = std::max(need_host, e->cap_host * 2 + 1024);
-    if (e->hF) (void)hipHostFree(e->hF);
-    if (e->hR) (void)hipHostFree(e->hR);
-    if (e->perm_stream) HIPOK(hipStreamSynchronize(e->perm_stream));   // a copy out of hrank may still be in flight
-    if (e->hrank) (void)hipHostFree(e->hrank);
-    HIPOK(hipHostMalloc((void**)&e->hF, nc));
-    HIPOK(hipHostMalloc((void**)&e->hR, nc));
-    HIPOK(hipHostMalloc((void**)&e->hrank, (size_t)nc * 4));
-    e->cap_host = nc;
-  }
-  int need_blocks = nblk(std::max(e->cap_v, e->cap_sched), BLK * CITEMS) + 1;
-  if (need_blocks > e->cap_blocks) {
-    { int rc = regrow(e, &e->block_counts, 0, (size_t)need_blocks); if (rc) return rc; }
-    e->cap_blocks = need_blocks;
-  }
-  return TS_OK;
-}
-
-int ensure_pool(E* e, size_t need_words) {
-  if (need_words <= e->pool_cap) return TS_OK;
-  size_t nc = std::max(need_words, e->pool_cap * 2 + (1u << 16));
-  if (nc >= (1ull << 32)) return fail(e, TS_E_CAPACITY, "path pool exceeds 2^32 words");
-  int rc = regrow(e, &e->d.pool, e->pool_used, nc);
-  if (rc) return rc;
-  e->pool_cap = nc;
-  e->d.pool_cap_words = nc;
-  return TS_OK;
-}
-
-int sync_counters(E* e) {  // device counters -> e->C
-  HIPOK(hipMemcpyAsync(e->hcnt, e->d.cnt, sizeof(DevCnt), hipMemcpyDeviceToHost, e->stream));
-  HIPOK(hipStreamSynchronize(e->stream));
-  const DevCnt& c = *e->hcnt;
-  e->C.stuck = c.stuck; e->C.collisions = c.collisions; e->C.malfunctions = c.malfunctions;
-  e->C.overtaking = c.overtaking; e->C.in_stuck_detour = c.in_stuck_detour; e->C.parked = c.parked;
-  e->C.live_internal = c.live_internal; e->C.live_through = c.live_through;
-  e->C.count_completed_internal = c.completed_internal; e->C.count_completed_through = c.completed_through;
-  e->C.total_distance_internal = c.dist_internal; e->C.total_distance_through = c.dist_through;
-  e->C.total_duration_internal = c.dur_internal; e->C.total_duration_through = c.dur_through;
-  e->C.astar_calls = c.astar_calls; e->C.astar_expansions = c.astar_exp; e->C.astar_relaxations = c.astar_relax;
-  return TS_OK;
-}
-
-// stable compaction of active_vehicle_agents (which = 0) or the schedule (which = 1); returns new length
-int compact(E* e, int which, int n, int* out_n) {
-  Dev& d = e->d;
-  int nb = nblk(n, BLK * CITEMS);
-  if (n == 0) { *out_n = 0; return TS_OK; }
-  int _tok = prof_begin(e, PK_COMPACT, n);
-  hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(BLK), 0, e->stream, d.active, d.sched_kind, n, which, e->block_counts);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, e->stream, e->block_counts, nb, e->d_total);
-  hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(BLK), 0, e->stream, d, n, which, e->block_counts, e->active_alt,
-                     e->kind_alt, e->ref_alt);
-  prof_end(e, _tok);
-  HIPOK(hipMemcpyAsync(e->hint, e->d_total, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIPOK(hipStreamSynchronize(e->stream));
-  *out_n = e->hint[0];
-  if (which == 0) std::swap(d.active, e->active_alt);
-  else { std::swap(d.sched_kind, e->kind_alt); std::swap(d.sched_ref, e->ref_alt); }
-  return TS_OK;
-}
-
-int pool_from_device(E* e) {
-  unsigned long long v = 0;
-  HIPOK(hipMemcpy(&v, &e->d.cnt->pool_used, sizeof(v), hipMemcpyDeviceToHost));
-  e->pool_used = (size_t)std::min<unsigned long long>(v, e->pool_cap);
-  return TS_OK;
-}
-int pool_to_device(E* e) {
-  unsigned long long v = e->pool_used;
-  HIPOK(hipMemcpy(&e->d.cnt->pool_used, &v, sizeof(v), hipMemcpyHostToDevice));
-  return TS_OK;
-}
-
-// scratch tiers for the GPU A*: many small searchers, fewer large ones, a handful that can hold the whole grid
-int ensure_tier(E* e, int t) {
-  if (e->tier_ready[t]) return TS_OK;
-  ATier& T = e->tier[t];
-  const long long N = e->N;
-  // nodes a search may touch per tier: 2048 / 32 768 / 262 144 / the whole map; the smaller a search's footprint,
-  // the more of them run side by side.  The last tier gets as many slots as ~16 GB of scratch allow (4 .. 64).
-  const long long caps[ts_engine::N_TIERS] = {std::min<long long>(N, 2048), std::min<long long>(N, 32768),
-                                              std::min<long long>(N, 262144), N};
-  const long long last_bytes = N * (2 * 16 + 4 * 17 + 5 * 4);   // table + heap + dir bytes + five cell buffers, per slot
-  const int last_slots = (int)std::max<long long>(4, std::min<long long>(64, (16ll << 30) / std::max<long long>(last_bytes, 1)));
-  // slots by a ~16 GB budget per tier (allocated on first use; small maps cap the per-slot size at N)
-  const int slots[ts_engine::N_TIERS] = {16384, 4096, 512, last_slots};
-  T.cap = (int)caps[t];
-  T.n_slots = slots[t];
-  uint32_t hs = 1;
-  while (hs < 2ull * (unsigned long long)T.cap) hs <<= 1;
-  T.hsize = hs;
-  T.heap_cap = (int)std::min<long long>(4ll * T.cap, 0x7FFFFFF0ll);
-  const size_t S = (size_t)T.n_slots;
-  HIPOK(dalloc(e, &T.ht, S * hs));
-  HIPOK(dalloc(e, &T.hq, S * T.heap_cap));
-  HIPOK(dalloc(e, &T.hd, S * T.heap_cap));
-  HIPOK(dalloc(e, &T.cells, S * ((size_t)5 * T.cap + 3 * MAXB)));
-  HIPOK(dalloc(e, &T.slot_epoch, S));
-  HIPOK(hipMemsetAsync(T.ht, 0, S * hs * sizeof(HEnt), e->stream));
-  HIPOK(hipMemsetAsync(T.slot_epoch, 0, S * 4, e->stream));
-  HIPOK(hipStreamSynchronize(e->stream));
-  e->tier_ready[t] = true;
-  return TS_OK;
-}
-
-// density_map as of the last tick start (city_model.py:1853), materialised only when a search may need it
-int ensure_density(E* e, const int8_t* occ_src) {
-  const size_t N = e->N;
-  if (!e->dens_t0) { HIPOK(dalloc(e, &e->dens_t0, N)); HIPOK(dalloc(e, &e->dens_t1, N)); }
-  if (!e->d.density) HIPOK(dalloc(e, &e->d.density, N));
-  const int r = e->P.vehicle_awareness_range;
-  int tok = prof_begin(e, PK_DENSITY, (long long)N);
-  hipLaunchKernelGGL(k_density_pass0, dim3(nblk((long long)N)), dim3(BLK), 0, e->stream, occ_src, e->d.is_road, e->W, e->H, r,
-                     e->dens_t0, e->dens_t1);
-  hipLaunchKernelGGL(k_density_pass1, dim3(nblk((long long)N)), dim3(BLK), 0, e->stream, e->dens_t0, e->dens_t1, e->W, e->H, r,
-                     e->d.density);
-  prof_end(e, tok);
-  return TS_OK;
-}
-
-// garbage-collect / grow the path pool so that at least `need_free` words are available
-int pool_make_room(E* e, size_t need_free) {
-  int rc = pool_from_device(e);
-  if (rc) return rc;
-  if (e->pool_used + need_free <= e->pool_cap && e->pool_used * 4 < e->pool_cap * 3) return TS_OK;
-  // copy the live words of every active vehicle into a fresh pool (twice as large if it was mostly live)
-  size_t new_cap = e->pool_cap;
-  for (int attempt = 0; attempt < 2; attempt++) {
-    if (new_cap >= (1ull << 32)) return fail(e, TS_E_CAPACITY, "path pool exceeds 2^32 words");
-    uint32_t* np = nullptr;
-    unsigned long long* used = nullptr;
-    HIPOK(dalloc(e, &np, new_cap));
-    HIPOK(dalloc(e, &used, 1));
-    HIPOK(hipMemsetAsync(used, 0, sizeof(unsigned long long), e->stream));
-    // the GC kernel rewrites offsets in place, so it can only run once per pool: size the target generously
-    if (attempt == 0 && e->pool_used * 2 > new_cap) { dfree(e, np); dfree(e, used); new_cap = std::min<size_t>(new_cap * 2, (1ull << 32) - 1); continue; }
-    if (e->n_active > 0)
-      hipLaunchKernelGGL(k_pool_gc, dim3(nblk(e->n_active)), dim3(BLK), 0, e->stream, e->d, e->n_active, np, used);
-    unsigned long long u = 0;
-    HIPOK(hipMemcpyAsync(&u, used, sizeof(u), hipMemcpyDeviceToHost, e->stream));
-    HIPOK(hipStreamSynchronize(e->stream));
-    dfree(e, e->d.pool);
-    dfree(e, used);
-    e->d.pool = np; e->pool_cap = new_cap; e->d.pool_cap_words = new_cap; e->pool_used = (size_t)u;
-    rc = pool_to_device(e);
-    if (rc) return rc;
-    break;
-  }
-  if (e->pool_used + need_free > e->pool_cap) {
-    rc = ensure_pool(e, (e->pool_used + need_free) * 2);
-    if (rc) return rc;
-  }
-  return TS_OK;
-}
-
-inline double now_ms();
 // k_decide_replan over the work lists.  Stage 0 keeps the search structures in LDS (one wave per vehicle), stages
 // 1-4 are the HBM tiers; a search that outgrows its stage moves to the next one, and k_decide_main queues every
 // vehicle directly on the stage its last search fitted in (Dev::tier_hint).
@@ -1506,489 +115,6 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   return TS_OK;
 }
 
-// random.shuffle(keys) with model.random: Fisher-Yates from the top with _randbelow's rejection
-// sampling, reading pre-generated words.  Two persistent threads form a pipeline: the first extracts the draws
-// (they depend only on the word stream and on n), the second applies the swaps a chunk behind it, copies every
-// finished stretch of the permutation (position i is final once element i has been swapped) into the pinned
-// buffer e->hrank and sends it to the device on its own stream.  Result: d_perm[q] = schedule slot stepping at
-// time q (inverted to rank[slot] by k_rank_invert), the clock agent's rank in rank_clock_host.
-constexpr int SH_CH = 1 << 12;
-void shuffle_draws(E* e, int n) {
-  if ((int)e->shuffle_j.size() < n + 64) e->shuffle_j.resize((size_t)n + 64);
-  uint32_t* jb = e->shuffle_j.data();   // jb[(n - 1) - i] = draw of element i
-  MTPipe& r = e->rng_sched;
-  uint64_t w = r.pos();
-  uint32_t cnt = 0;
-  for (int hi = n - 1; hi >= 1; hi -= SH_CH) {
-    const int lo = std::max(1, hi - SH_CH + 1);
-    r.need((uint64_t)(hi - lo + 1) * 4 + 512 + (w - r.pos()));
-    uint64_t limit = w + (uint64_t)(hi - lo + 1) * 4 + 256;
-    // Walk the WORDS in order (addresses are not data dependent, so the loads pipeline): a word is the draw of the
-    // current element if it is below i + 1, otherwise it is a rejected try.  The only loop-carried state is the
-    // element counter.
-    uint32_t nn = (uint32_t)hi + 1;             // i + 1 of the element being drawn
-    const uint32_t nn_end = (uint32_t)lo;       // stop once nn == lo  (element lo - 1 is not ours)
-    while (nn > nn_end) {
-      const int shift = __builtin_clz(nn);      // 32 - bit_length(nn); constant while nn >= 2^(k-1)
-      const uint32_t band_end = std::max(nn_end, (1u << (31 - shift)) - 1u);  // last nn of this band, exclusive
-      while (nn > band_end) {
-        if (w + 256 >= limit) { r.advance_to(w); r.need(8192); limit = w + 8192 - 256; }
-        int burst = 64;   // a short unrolled burst; bounds: at most 64 elements / words per burst
-        while (burst-- > 0 && nn > band_end) {
-          const uint32_t c = r.at(w++) >> shift;
-          const uint32_t acc = c < nn;
-          jb[cnt] = c;
-          cnt += acc;
-          nn -= acc;
-        }
-      }
-    }
-    r.advance_to(w);
-    e->sh_progress.store((int)cnt, std::memory_order_release);
-  }
-}
-void shuffle_swaps(E* e, int n) {
-  e->perm.resize(n);
-  uint32_t* p = e->perm.data();  // ordinary cached memory, first touched by this thread
-  for (int i = 0; i < n; i++) p[i] = (uint32_t)i;
-  const uint32_t cs = e->clock_slot >= 0 ? (uint32_t)e->clock_slot : 0xFFFFFFFFu;
-  uint32_t cpos = cs;
-  const int total = std::max(0, n - 1);
-  int done = 0, sent_hi = n;   // positions [sent_hi, n) are already on their way to the device
-  auto send = [&](int lo) {    // positions [lo, sent_hi) are final
-    if (lo >= sent_hi) return;
-    memcpy(e->hrank + lo, p + lo, (size_t)(sent_hi - lo) * 4);
-    if (hipMemcpyAsync(e->d_perm + lo, e->hrank + lo, (size_t)(sent_hi - lo) * 4, hipMemcpyHostToDevice, e->perm_stream) != hipSuccess)
-      e->sh_err = 1;
-    sent_hi = lo;
-  };
-  while (done < total) {
-    const int avail = e->sh_progress.load(std::memory_order_acquire);
-    if (avail <= done) { std::this_thread::yield(); continue; }
-    const int m = std::min(avail - done, SH_CH);
-    const uint32_t* jb = e->shuffle_j.data() + done;
-    for (int q = 0; q < m; q++) __builtin_prefetch(&p[jb[q]], 1, 1);
-    const int hi = n - 1 - done;
-    for (int q = 0; q < m; q++) {
-      const int i = hi - q;
-      const uint32_t j = jb[q];
-      const uint32_t a = p[i], b = p[j];
-      p[i] = b; p[j] = a;
-      if (a == cs) cpos = j; else if (b == cs) cpos = (uint32_t)i;
-    }
-    done += m;
-    if (sent_hi - (n - done) >= (1 << 18)) send(n - done);
-  }
-  send(0);
-  if (hipEventRecord(e->perm_ev, e->perm_stream) != hipSuccess) e->sh_err = 1;
-  e->rank_clock_host = cs == 0xFFFFFFFFu ? 0xFFFFFFFFu : cpos;
-}
-
-// persistent workers for the scheduler shuffle (fresh std::threads per tick cost ~50 us each and lose locality)
-void shuffle_worker(E* e, int role) {
-  if (role == 1) (void)hipSetDevice(e->device);
-  std::unique_lock<std::mutex> lk(e->sh_mu);
-  unsigned seen = 0;
-  for (;;) {
-    e->sh_cv.wait(lk, [&]() { return e->sh_gen != seen || e->sh_quit; });
-    if (e->sh_quit) return;
-    seen = e->sh_gen;
-    const int n = e->sh_n;
-    lk.unlock();
-    const double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (role == 0) shuffle_draws(e, n); else shuffle_swaps(e, n);
-    const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
-    lk.lock();
-    if (role == 1) { e->shuffle_ms = dt; e->sh_done = true; e->sh_cv.notify_all(); }
-  }
-}
-void shuffle_start(E* e, int n) {
-  if (!e->sh_thread.joinable()) { e->sh_thread = std::thread(shuffle_worker, e, 0); e->sh2_thread = std::thread(shuffle_worker, e, 1); }
-  std::lock_guard<std::mutex> lk(e->sh_mu);
-  e->sh_progress.store(0, std::memory_order_relaxed);
-  e->sh_n = n; e->sh_done = false; e->sh_gen++;
-  e->sh_cv.notify_all();
-}
-void shuffle_wait(E* e) {
-  std::unique_lock<std::mutex> lk(e->sh_mu);
-  e->sh_cv.wait(lk, [e]() { return e->sh_done; });
-}
-
-// a host-side agent (rain manager = id 0, rain clouds = ids 1..) gets a row in the device table of schedule slots
-int host_agent_register(E* e, int slot) {
-  const int hid = e->n_host_agents;
-  if (hid + 1 > e->cap_hslot) {
-    int nc = std::max(64, e->cap_hslot * 2);
-    int rc = regrow(e, &e->d.hslot, (size_t)e->n_host_agents, (size_t)nc);
-    if (rc) return rc;
-    e->cap_hslot = nc;
-  }
-  HIPOK(hipMemcpy(e->d.hslot + hid, &slot, 4, hipMemcpyHostToDevice));
-  e->n_host_agents++;
-  return TS_OK;
-}
-
-// math.hypot of CPython 3.10 (Modules/mathmodule.c vector_norm); libm's hypot can differ in the last bit
-double py_hypot(double a, double b) {
-  double vec[2] = {std::fabs(a), std::fabs(b)};
-  double max = vec[0] > vec[1] ? vec[0] : vec[1];
-  if (max == 0.0) return 0.0;
-  const double T27 = 134217729.0;
-  double x, scale, oldcsum, csum = 1.0, frac1 = 0.0, frac2 = 0.0, frac3 = 0.0, t, hi, lo, h;
-  int max_e;
-  std::frexp(max, &max_e);
-  scale = std::ldexp(1.0, -max_e);
-  for (int i = 0; i < 2; i++) {
-    x = vec[i]; x *= scale;
-    t = x * T27; hi = t - (t - x); lo = x - hi;
-    x = hi * hi; oldcsum = csum; csum += x; frac1 += (oldcsum - csum) + x;
-    x = 2.0 * hi * lo; oldcsum = csum; csum += x; frac2 += (oldcsum - csum) + x;
-    frac3 += lo * lo;
-  }
-  h = std::sqrt(csum - 1.0 + (frac1 + frac2 + frac3));
-  x = h; t = x * T27; hi = t - (t - x); lo = x - hi;
-  x = -hi * hi; oldcsum = csum; csum += x; frac1 += (oldcsum - csum) + x;
-  x = -2.0 * hi * lo; oldcsum = csum; csum += x; frac2 += (oldcsum - csum) + x;
-  x = -lo * lo; oldcsum = csum; csum += x; frac3 += (oldcsum - csum) + x;
-  x = csum - 1.0 + (frac1 + frac2 + frac3);
-  return (h + x / (2.0 * h)) / scale;
-}
-
-// RainManager.add_random_rain (rain.py:100-148) + RainAgent.__init__ (24-57) + schedule.add(rain)
-int rain_add_random(E* e) {
-  MTPipe& r = e->rng_global;
-  const double w = e->W, h = e->H, off = e->P.rain_spawn_offset;
-  const int edge = (int)r.randbelow(4);  // random.choice(['N', 'S', 'E', 'W'])
-  double x0, y0, xt, yt;
-  int corner;  // 0 NW, 1 NE, 2 SW, 3 SE
-  if (edge == 0) { x0 = 0.0 + (w - 0.0) * r.random(); y0 = h - off; corner = r.randbelow(2) ? 3 : 2; }
-  else if (edge == 1) { x0 = 0.0 + (w - 0.0) * r.random(); y0 = off; corner = r.randbelow(2) ? 1 : 0; }
-  else if (edge == 2) { x0 = w - off; y0 = 0.0 + (h - 0.0) * r.random(); corner = r.randbelow(2) ? 2 : 0; }
-  else { x0 = off; y0 = 0.0 + (h - 0.0) * r.random(); corner = r.randbelow(2) ? 3 : 1; }
-  if (corner == 0) { xt = 0; yt = h; } else if (corner == 1) { xt = w; yt = h; } else if (corner == 2) { xt = 0; yt = 0; } else { xt = w; yt = 0; }
-  double dx = xt - x0, dy = yt - y0;
-  double length = py_hypot(dx, dy);
-  if (length == 0.0) length = 1.0;
-  dx /= length; dy /= length;
-  ts_engine::Rain c;
-  c.x = x0; c.y = y0;
-  double l2 = py_hypot(dx, dy);
-  if (l2 == 0.0) l2 = 1.0;
-  c.dx = dx / l2; c.dy = dy / l2;
-  c.radius = r.randint(e->P.rain_radius_min, e->P.rain_radius_max);
-  // schedule.add(rain): a new entry at the end of the schedule (it does not step in the tick that created it)
-  if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
-  int rc = ensure_vehicle_capacity(e, e->cap_v, e->n_sched + 1);
-  if (rc) return rc;
-  const int hid = e->n_host_agents;
-  rc = host_agent_register(e, e->n_sched);
-  if (rc) return rc;
-  const int8_t kind = K_RAIN;
-  HIPOK(hipMemcpy(e->d.sched_kind + e->n_sched, &kind, 1, hipMemcpyHostToDevice));
-  HIPOK(hipMemcpy(e->d.sched_ref + e->n_sched, &hid, 4, hipMemcpyHostToDevice));
-  e->n_sched++;
-  e->mixed_order = true;
-  e->rains.push_back(hid);
-  e->rains_all.resize((size_t)hid);   // ids are 1-based behind the manager
-  e->rains_all[(size_t)hid - 1] = c;
-  e->rain_counter++;
-  return TS_OK;
-}
-
-// RainManager.step (rain.py:156-184); the discs it saw are what rain_map becomes
-int rain_manager_step(E* e, RainDiscs& discs) {
-  if (e->rain_cooldown_left > 0) e->rain_cooldown_left--;
-  if ((int)e->rains.size() < e->P.rain_occurrences_max && e->rain_cooldown_left == 0 &&
-      e->rng_global.random() < e->P.rain_spawn_chance) {
-    int rc = rain_add_random(e);
-    if (rc) return rc;
-  }
-  discs.n = 0;
-  for (int hid : e->rains) {
-    const auto& c = e->rains_all[(size_t)hid - 1];
-    if (!c.stepped) continue;   // covered_cells is empty until the cloud's first step
-    if (discs.n >= 16) return fail(e, TS_E_CAPACITY, "more than 16 rain clouds");
-    discs.cx[discs.n] = c.cx; discs.cy[discs.n] = c.cy; discs.r[discs.n] = c.radius; discs.n++;
-  }
-  return TS_OK;
-}
-
-// RainAgent.step (rain.py:60-84).  Returns 1 if the cloud left the map (schedule.remove(self)).
-int rain_agent_step(E* e, int hid) {
-  auto& c = e->rains_all[(size_t)hid - 1];
-  c.x += c.dx; c.y += c.dy;
-  c.cx = (int)c.x; c.cy = (int)c.y;   // int(): truncation toward zero
-  c.stepped = true;
-  const int R = c.radius;
-  if (c.x < -R || c.x > e->W + R || c.y < -R || c.y > e->H + R) {
-    // on_rain_exit runs while the cloud is still in city_model.rains: `not rains` is never true there, so the
-    // cooldown never starts (rain.py:150-154)
-    for (size_t k = 0; k < e->rains.size(); k++) if (e->rains[k] == hid) { e->rains.erase(e->rains.begin() + k); break; }
-    c.alive = false;
-    return 1;
-  }
-  return 0;
-}
-
-// _generate_day (dynamic_traffic_generator.py:307-396): internal, service and through trips of one day
-void generate_day(E* e, int day_idx) {
-  auto& G = e->gen;
-  MTPipe& r = e->rng_global;
-  // compute_quotas (319-331): floors, then +1 for the largest fractional parts (stable, descending)
-  auto quotas = [&](int total) {
-    const int nz = G.T.n_zones;
-    std::vector<double> fc(nz);
-    std::vector<int> fl(nz), order(nz);
-    long long sum = 0;
-    for (int z = 0; z < nz; z++) {
-      fc[z] = (double)total * G.T.zones[z].through_distribution;
-      fl[z] = (int)std::floor(fc[z]); sum += fl[z]; order[z] = z;
-    }
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int a, int b) { return fc[a] - std::floor(fc[a]) > fc[b] - std::floor(fc[b]); });
-    const long long rem = total - sum;
-    for (long long i = 0; i < rem && i < nz; i++) fl[order[i]] += 1;
-    return fl;
-  };
-  const std::vector<int> food_q = quotas(G.T.total_service_vehicles_food), waste_q = quotas(G.T.total_service_vehicles_waste);
-  for (int zi = 0; zi < G.T.n_zones; zi++) {
-    const TsTrafficZone& z = G.T.zones[zi];
-    const double z0 = (double)((long long)day_idx * 86400 + (long long)z.start_hour * 3600 - G.T.start_offset_seconds);
-    const double z1 = (double)((long long)day_idx * 86400 + (long long)z.end_hour * 3600 - G.T.start_offset_seconds);
-    const double span = z1 - z0;
-    for (int k = 0; k < z.n_internal; k++) {
-      const long long cnt = (long long)std::nearbyint((double)G.T.internal_population_per_day * z.fraction[k]);
-      if (cnt == 0) continue;
-      std::vector<int> origins, dests;
-      for (size_t b = 0; b < G.blk_type.size(); b++) {
-        if (G.blk_type[b] == z.origin_type[k]) origins.push_back((int)b);
-        if (G.blk_type[b] == z.dest_type[k]) dests.push_back((int)b);
-      }
-      if (origins.empty() || dests.empty()) continue;
-      for (long long q = 0; q < cnt; q++) {
-        const double t = z0 + r.random() * span;
-        const int ob = origins[r.randbelow((uint32_t)origins.size())];
-        const int db = dests[r.randbelow((uint32_t)dests.size())];
-        const int oc = G.blk_entr[ob][r.randbelow((uint32_t)G.blk_entr[ob].size())];
-        const int dc = G.blk_entr[db][r.randbelow((uint32_t)G.blk_entr[db].size())];
-        G.pending.push_back(ts_engine::Trip{oc, dc, t, TS_POP_INTERNAL});
-      }
-    }
-    // service vehicles, uniform per zone (362-376): one entrance draw per trip
-    const int Nf = food_q[zi], Nw = waste_q[zi];
-    for (int j = 1; j <= Nf; j++) {
-      const double t = z0 + (double)((long long)j * (long long)span) / (double)(Nf + 1);
-      const int sc = G.hw_in[r.randbelow((uint32_t)G.hw_in.size())];
-      G.pending.push_back(ts_engine::Trip{sc, -1, t, TS_TRIP_SERVICE_FOOD});
-    }
-    for (int j = 1; j <= Nw; j++) {
-      const double t = z0 + (double)((long long)j * (long long)span) / (double)(Nw + 1);
-      const int sc = G.hw_in[r.randbelow((uint32_t)G.hw_in.size())];
-      G.pending.push_back(ts_engine::Trip{sc, -1, t, TS_TRIP_SERVICE_WASTE});
-    }
-    long long thr = (long long)std::nearbyint((double)G.T.passing_population_per_day * z.through_distribution);
-    thr -= Nf + Nw;   // SERVICE_VEHICLES_COUNT_AS_THROUGH defaults to True (90, 381-382)
-    for (long long q = 0; q < thr; q++) {
-      const double t = z0 + r.random() * span;
-      const int ent = G.hw_in[r.randbelow((uint32_t)G.hw_in.size())];
-      const int ex = G.hw_out[r.randbelow((uint32_t)G.hw_out.size())];
-      G.pending.push_back(ts_engine::Trip{ent, ex, t, TS_POP_THROUGH});
-    }
-  }
-}
-
-
-// ------------------------------ city blocks + service vehicles (host state) -------------------------------
-// CityBlock.step (city_block.py:110-150)
-void block_step(E* e, int bi) {
-  if (bi >= (int)e->blocks.size()) return;
-  auto& b = e->blocks[bi];
-  const TsTrafficTables& T = e->gen.T;
-  if (b.needs_food) {
-    if (T.gradual_city_block_resources) {
-      b.food_rem += b.food_rate;
-      if (b.food_rem >= 1.0) { const double whole = std::trunc(b.food_rem); b.food = std::max(b.food - whole, 0.0); b.food_rem -= whole; }
-    } else if (++b.ticks_since_food >= T.food_consumption_ticks) {
-      b.food = std::max(b.food - (double)b.cells, 0.0); b.ticks_since_food = 0;
-    }
-  }
-  if (b.produces_waste) {
-    if (T.gradual_city_block_resources) {
-      b.waste_rem += b.waste_rate;
-      if (b.waste_rem >= 1.0) { const double whole = std::trunc(b.waste_rem); b.waste = std::min(b.waste + whole, b.max_waste); b.waste_rem -= whole; }
-    } else if (++b.ticks_since_waste >= T.waste_production_ticks) {
-      b.waste = std::min(b.waste + (double)b.cells, b.max_waste); b.ticks_since_waste = 0;
-    }
-  }
-}
-
-// CityBlock.get_service_road_cell step 4 (city_block.py:192-202): first ranked cell without a parked vehicle
-int service_road_cell(E* e, int bi) {
-  for (int c : e->blocks[bi].service_cells) {
-    auto it = e->parked_cells.find(c);
-    if (it == e->parked_cells.end() || it->second <= 0) return c;
-  }
-  return -1;
-}
-
-int svc_find(E* e, int vid) {
-  for (size_t k = 0; k < e->svc.size(); k++) if (e->svc[k].vid == vid) return (int)k;
-  return -1;
-}
-
-// ServiceVehicleAgent._start_service, host part (vehicle_service.py:85-104); `pos` = the cell it parked on
-void svc_start(E* e, ts_engine::SvcVeh& v) {
-  if (v.phase != 0 || v.block < 0) {   // a vehicle that merely parks (base on_target_reached with remove_on_arrival False)
-    e->parked_cells[v.target]++;
-    return;
-  }
-  e->parked_cells[v.target]++;
-  v.pos = v.target;
-  auto& b = e->blocks[v.block];
-  if (v.type == TS_TRIP_SERVICE_FOOD) {
-    const double need = b.max_food - b.food;
-    const double amt = std::min(v.load, need);
-    b.food = std::min(b.food + amt, b.max_food);
-    v.load -= amt;
-  } else {
-    const double surplus = b.waste;
-    const double cap = v.max_load - v.load;
-    const double amt = std::min(cap, surplus);
-    b.waste = std::max(b.waste - amt, 0.0);
-    v.load += amt;
-  }
-  v.ticks = e->gen.T.service_load_time;
-  v.phase = 1;
-}
-
-// ServiceVehicleAgent._finish_service (vehicle_service.py:106-141) at the vehicle's place in the shuffled order:
-// every lower-ranked agent has stepped on the device, every higher-ranked one has not
-int svc_finish(E* e, ts_engine::SvcVeh& v) {
-  auto& G = e->gen;
-  { auto it = e->parked_cells.find(v.pos); if (it != e->parked_cells.end() && --it->second <= 0) e->parked_cells.erase(it); }
-  const bool more = v.type == TS_TRIP_SERVICE_FOOD ? v.load > 0 : v.load < v.max_load;
-  int target = -1, to_block = 0;
-  if (more) {
-    int nb = -1;   // get_block_most_in_need_of_food / _waste_pickup (city_model.py:2078-2087): stable sort, first element
-    for (size_t b = 0; b < e->blocks.size(); b++) {
-      const auto& B = e->blocks[b];
-      if (v.type == TS_TRIP_SERVICE_FOOD) { if (B.needs_food && (nb < 0 || B.food < e->blocks[nb].food)) nb = (int)b; }
-      else { if (B.produces_waste && (nb < 0 || B.waste > e->blocks[nb].waste)) nb = (int)b; }
-    }
-    if (nb >= 0) {
-      v.block = nb;
-      target = service_road_cell(e, nb);
-      if (target < 0) {
-        e->fatal = TS_E_UNSUPPORTED;
-        return fail(e, TS_E_UNSUPPORTED, "service vehicle: every service road cell of the next block holds a parked vehicle (the reference raises)");
-      }
-      to_block = 1;
-    }
-  }
-  if (!to_block) {
-    int best_d = 0;
-    for (int c : G.hw_out) {   // min(exits, key=manhattan): first minimum
-      const int dd = std::abs(c % e->W - v.pos % e->W) + std::abs(c / e->W - v.pos / e->W);
-      if (target < 0 || dd < best_d) { target = c; best_d = dd; }
-    }
-    if (target < 0) { e->fatal = TS_E_UNSUPPORTED; return fail(e, TS_E_UNSUPPORTED, "service vehicle without highway exits (the reference raises)"); }
-  }
-  hipLaunchKernelGGL(k_svc_finish, dim3(1), dim3(64), 0, e->stream, e->d, e->P, v.vid, target, to_block);
-  v.target = target;
-  v.phase = to_block ? 0 : 2;
-  return plan_vehicle(e, v.vid, v.pos, target);
-}
-
-// _spawn for service trips (dynamic_traffic_generator.py:419-430) + ServiceVehicleAgent.__init__ (vehicle_service.py:19-41)
-// `id` = index into the fleet's id pool, -1 for a vehicle the UI created with an id of its own
-int spawn_service_at(E* e, int origin, int kind, int id) {
-  auto& G = e->gen;
-  const bool food = kind == TS_TRIP_SERVICE_FOOD;
-  // _find_initial_target (62-83): `attempt` is never advanced, so only valid_blocks[0] is ever tried
-  int blk = -1;
-  for (size_t b = 0; b < e->blocks.size(); b++)
-    if (food ? e->blocks[b].needs_food : e->blocks[b].produces_waste) { blk = (int)b; break; }
-  int target, phase;
-  if (blk >= 0) {
-    target = service_road_cell(e, blk);
-    if (target < 0) {
-      e->fatal = TS_E_UNSUPPORTED;
-      return fail(e, TS_E_UNSUPPORTED, "service vehicle: no free service road cell at its first block (the reference loops forever)");
-    }
-    phase = 0;
-  } else {
-    if (G.hw_out.empty()) { e->fatal = TS_E_UNSUPPORTED; return fail(e, TS_E_UNSUPPORTED, "service vehicle without highway exits (IndexError in the reference)"); }
-    target = G.hw_out[0];
-    phase = 2;
-  }
-  if (id >= 0) {
-    char& live = e->sv_live[(size_t)(food ? 0 : G.T.total_service_vehicles_food) + id];
-    if (live) {   // BaseScheduler.add raises on a unique_id that is already scheduled (Mesa <= 2.1)
-      e->fatal = TS_E_UNSUPPORTED;
-      return fail(e, TS_E_UNSUPPORTED, "service vehicle id drawn while a vehicle with that id is still live (the scheduler raises in the reference)");
-    }
-    live = 1;
-  }
-  if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
-  if (!e->d.arr) {   // first service vehicle of this engine: the record buffer the kernels report arrivals in
-    e->d.arr_cap = 1 << 16;
-    HIPOK(dalloc(e, &e->d.arr, (size_t)e->d.arr_cap * 3));
-  }
-  int rc = add_vehicle_planned(e, origin, target, TS_POP_THROUGH);
-  if (rc) return rc;
-  const int vid = e->n_vehicles_total - 1;
-  hipLaunchKernelGGL(k_flags_or, dim3(1), dim3(64), 0, e->stream, e->d, vid, (int)(VF_SVC | VF_KEEP | (phase == 0 ? VF_TOBLOCK : 0)));
-  ts_engine::SvcVeh v;
-  v.vid = vid; v.type = kind; v.id = id; v.block = blk;
-  v.max_load = food ? G.T.service_max_load_food : G.T.service_max_load_waste;
-  v.load = food ? v.max_load : 0.0;
-  v.phase = phase; v.ticks = 0; v.pos = origin; v.target = target;
-  e->svc.push_back(v);
-  if (food) e->C.live_service_food++; else e->C.live_service_waste++;
-  return TS_OK;
-}
-int spawn_service(E* e, const ts_engine::Trip& t) {
-  auto& G = e->gen;
-  const bool food = t.kind == TS_TRIP_SERVICE_FOOD;
-  if (food) e->C.created_service_food++; else e->C.created_service_waste++;
-  const int pool = food ? G.T.total_service_vehicles_food : G.T.total_service_vehicles_waste;
-  const int id = (int)e->rng_global.randbelow((uint32_t)pool);   // vid = random.choice(pool)
-  return spawn_service_at(e, t.origin, t.kind, id);
-}
-
-// DynamicTrafficAgent.step (153-194) and _spawn (398-416), executed at the agent's place in the shuffled order:
-// every lower-ranked agent has stepped on the device, every higher-ranked one has not yet.
-int generator_step(E* e) {
-  auto& G = e->gen;
-  const double prev = e->C.elapsed;
-  e->C.elapsed += e->P.time_per_step_seconds;
-  const double total_secs = G.T.start_offset_seconds + e->C.elapsed;
-  const int new_day = (int)std::floor(total_secs / 86400.0);
-  if (new_day > G.current_day) {
-    for (int dd = G.current_day + 1; dd <= new_day; dd++) generate_day(e, dd);
-    G.current_day = new_day;
-    e->C.created_internal = 0; e->C.created_through = 0;
-    e->C.created_service_food = 0; e->C.created_service_waste = 0;
-  }
-  std::vector<ts_engine::Trip> keep, spawn;
-  for (const auto& t : G.pending) (prev < t.depart && t.depart <= e->C.elapsed ? spawn : keep).push_back(t);
-  G.pending.swap(keep);
-  for (const auto& t : spawn) {
-    if (t.kind == TS_TRIP_SERVICE_FOOD || t.kind == TS_TRIP_SERVICE_WASTE) {
-      int rc = spawn_service(e, t);
-      if (rc) return rc;
-      continue;
-    }
-    if (t.kind == TS_POP_INTERNAL) e->C.created_internal++; else e->C.created_through++;
-    (void)e->rng_global.randint(0, 9999);  // the id suffix of "V_{depart:06d}_{randint(0, 9999):04d}"
-    if (t.origin == t.dest) return fail(e, TS_E_UNSUPPORTED, "generated trip with origin == destination");
-    if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
-    int rc = add_vehicle_planned(e, t.origin, t.dest, t.kind);
-    if (rc) return rc;
-  }
-  return TS_OK;
-}
-
 // mirror the global stream's tempered words [uploaded, upto) into the device ring (copy stream + event)
 int words_upload(E* e, uint64_t upto) {
   MTPipe& r = e->rng_global;
@@ -2011,13 +137,6 @@ int words_upload(E* e, uint64_t upto) {
   return TS_OK;
 }
 
-inline double now_ms() {
-  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-inline void host_prof(E* e, int id, double ms, long long items) {
-  if (!e->prof) return;
-  e->prof_ms[id] += ms; e->prof_launches[id]++; e->prof_items[id] += items;
-}
 
 int tick(E* e) {
   Dev& d = e->d;
