@@ -586,10 +586,73 @@ def run_mt():
     print("[mt] ok")
 
 
+# world-only fixtures for trafficsimulation_amd/worldgen.py: (tag, width, height, seed, CityModel kwargs, Defaults overrides)
+WORLD_CASES = [
+    ("default200", 200, 200, 101, {}, {}),
+    ("rect", 120, 90, 102, {}, {}),
+    ("tall", 70, 130, 120, {}, {}),
+    ("ring_r3", 96, 96, 103, dict(ring_road_type="R3"), {}),
+    ("ring_r1", 96, 96, 104, dict(ring_road_type="R1"), {}),
+    ("ring_none", 96, 96, 105, dict(ring_road_type=None), {}),
+    ("unoptimised", 96, 96, 106, dict(optimized_intersections=False), {}),
+    ("fwd_range", 128, 128, 107, dict(forward_traffic_light_range=True, forward_traffic_light_range_intersections="Include in Range"), {}),
+    ("fwd_extra", 128, 128, 108, dict(forward_traffic_light_range=True, forward_traffic_light_range_intersections="Include as Extra"), {}),
+    ("fwd_skip", 128, 128, 109, dict(forward_traffic_light_range=True), {}),
+    ("carve_plain", 128, 128, 110, dict(carve_subblock_roads=True, subblock_roads_have_intersections=False, subblock_chance=1.0), {}),
+    ("carve_dense", 128, 128, 111, dict(carve_subblock_roads=True, subblock_chance=1.0, min_subblock_spacing=3), {}),
+    ("carve_r2", 128, 128, 121, dict(carve_subblock_roads=True, subblock_chance=0.8, subblock_road_type="R2"), {}),
+    ("entrance_lvl1", 96, 96, 112, {}, dict(BLOCK_ENTRANCE_ROAD_LEVEL=1)),
+    ("entrance_lvl2", 96, 96, 113, {}, dict(BLOCK_ENTRANCE_ROAD_LEVEL=2)),
+    ("thin_wall", 80, 80, 114, dict(wall_thickness=5, sidewalk_ring_width=1, highway_offset_from_edges=3), {}),
+    ("tight_blocks", 160, 160, 115, dict(min_block_spacing=4, max_block_spacing=8, r1_chance_mean=0.3, r2_chance_mean=0.4), {}),
+    ("no_min_r1", 96, 96, 116, dict(min_r1_bands=0), {}),
+    ("three_r1", 128, 128, 117, dict(min_r1_bands=3), {}),
+    ("short_lights", 72, 72, 118, dict(traffic_light_range=2), {}),
+    ("dummies", 64, 64, 119, dict(use_dummy_agents=True), {}),
+    ("mostly_r3", 128, 128, 122, dict(r1_chance_mean=0.05, r2_chance_mean=0.2), {}),
+] + [(f"seed{sd}", sz, sz, sd, {}, {}) for sd, sz in ((201, 64), (202, 64), (203, 80), (204, 96), (205, 96), (206, 112), (207, 128), (208, 144))]
+
+
+def run_worlds():
+    """tests/golden/worlds.npz: world tables + global stream state after CityModel.__init__ for WORLD_CASES."""
+    import numpy as np
+    _setup_paths()
+    import random
+    from Simulation.config import Defaults
+    Defaults.SAVE_TOTAL_RESULTS = False
+    Defaults.SAVE_INDIVIDUAL_RESULTS = False
+    Defaults.RAIN_ENABLED = False
+    Defaults.ENABLE_TRAFFIC = False
+    from Simulation.city_model import CityModel
+    out, index = {}, []
+    for tag, w, h, seed, kw, dfl in WORLD_CASES:
+        saved = {k: getattr(Defaults, k) for k in dfl}
+        for k, v in dfl.items():
+            setattr(Defaults, k, v)
+        random.seed(seed)
+        entry = dict(tag=tag, width=w, height=h, seed=seed, kwargs=kw, defaults=dfl)
+        try:
+            m = CityModel(width=w, height=h, seed=seed, **kw)
+            t = world_tables(m)
+            t["global_rng_state"] = np.asarray(random.getstate()[1], dtype=np.uint32)
+            for k, v in t.items():
+                out[f"{tag}/{k}"] = v
+        except Exception as e:  # the reference itself rejects this configuration
+            entry["raises"] = type(e).__name__
+            print(f"[worlds] {tag}: reference raised {type(e).__name__}: {e}")
+        for k, v in saved.items():
+            setattr(Defaults, k, v)
+        index.append(entry)
+        print(f"[worlds] {tag} done")
+    out["index"] = np.asarray(json.dumps(index))
+    np.savez_compressed(os.path.join(HERE, "worlds.npz"), **out)
+    print("[worlds] ok")
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "all":
-        jobs = ["mt", "density", "astar_kats"] + list(SCENARIOS)
+        jobs = ["mt", "density", "astar_kats", "worlds"] + list(SCENARIOS)
         for j in jobs:
             subprocess.run([sys.executable, os.path.abspath(__file__), j], check=True, cwd="/tmp")
         return
@@ -599,6 +662,8 @@ def main():
         run_density()
     elif what == "astar_kats":
         run_astar_kats()
+    elif what == "worlds":
+        run_worlds()
     else:
         run_scenario(what)
 

@@ -1,0 +1,25 @@
+"""size + seed -> worldgen -> HIP engine: the reference's own per-tick trace, with nothing taken from the fixture but
+the expected results (the CPU-oracle twin of this test is tests/test_worldgen.py)."""
+import pytest
+
+from trafficsimulation_amd.world import load_trace
+from tests.test_worldgen import _seed_only
+from tests.trace_util import check_initial, replay_and_compare, setup_from_trace, trace_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def hip():
+    from trafficsimulation_amd._lib import new_engine
+    api = new_engine()
+    yield api
+    api.close()
+
+
+@pytest.mark.parametrize("name,ticks", [("config1_64_s11", 300), ("config5_96_s17", 150), ("rain_96_s14", 120)])
+def test_seed_only_run_reproduces_reference_trace(hip, name, ticks):
+    tr = _seed_only(load_trace(trace_path(name)))
+    setup_from_trace(hip, tr)
+    check_initial(hip, tr)
+    assert replay_and_compare(hip, tr, ticks=ticks) == ticks

@@ -184,3 +184,24 @@ def test_facade_light_group_links_over_oracle(oracle):
     m.step()
     with pytest.raises(NotImplementedError):
         g.get_intermediate_groups()
+
+
+def test_facade_builds_reference_world_from_seed(oracle):
+    """CityModel(width, height, seed=...) with nothing else: world-gen, the state it leaves the global stream in, day 0
+    of the traffic generator and the first ticks are those of the reference's run with random.seed(11)."""
+    import json
+    tr = load_trace(trace_path("config1_64_s11"))
+    dta = json.loads(str(tr["dta_params"]))
+    m = CityModel(64, 64, seed=11, defaults=tr["defaults_json"], engine=oracle, traffic=dta)
+    for k in ("allowed_dirs_map", "is_road_map", "road_type_map", "intersection_map"):
+        assert np.array_equal(getattr(m, k), tr[k])
+    assert [c.position for c in m.block_entrances] == [tuple(p) for p in tr["block_entrances_xy"]]
+    for i, (s, g) in enumerate(zip(tr["v_start_xy"], tr["v_goal_xy"])):
+        VehicleAgent(f"gv_{i}", m, m.cell(int(s[0]), int(s[1])), m.cell(int(g[0]), int(g[1])), population_type="through")
+    H, W = m.height, m.width
+    for t in range(60):
+        m.step()
+        want = tr["veh_rows"][tr["veh_off"][t]:tr["veh_off"][t + 1]]
+        assert [v._spawn_idx for v in m.active_vehicle_agents] == list(want[:, 0])
+        assert np.array_equal(m.occupancy_map, np.unpackbits(tr["occ_t"][t])[:H * W].reshape(H, W))
+        assert np.array_equal(m.rain_map, np.unpackbits(tr["rain_t"][t])[:H * W].reshape(H, W))
