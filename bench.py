@@ -45,10 +45,14 @@ POLICY = {
 }
 
 
-def make_workload(size, vehicles, seed):
+def make_workload(size, vehicles, seed, world="synthetic"):
     from trafficsimulation_amd import citygen
     t0 = time.time()
-    tables = citygen.generate(size, size, seed=seed)
+    if world == "reference":    # the reference's own city for (size, seed): exact but interpreted, minutes at 4096^2
+        from trafficsimulation_amd import worldgen
+        tables = worldgen.generate_world(size, size, seed=seed, rain_enabled=False, enable_traffic=False)
+    else:
+        tables = citygen.generate(size, size, seed=seed)
     t1 = time.time()
     lo, hi = (150, 400) if size >= 1024 else (30, 120)
     routes = citygen.make_routes(tables, vehicles, seed=seed + 1, min_len=lo, max_len=hi)
@@ -86,6 +90,8 @@ def main():
     ap.add_argument("--policy", choices=["config2", "lights", "full"], default="config2",
                     help="config2 = car-following + movement only (BASELINE config 2); full = reference defaults: "
                          "QUEUE_ACTUATED lights, replanning (GPU A*), contraflow, malfunctions (BASELINE config 3)")
+    ap.add_argument("--world", choices=["synthetic", "reference"], default="synthetic",
+                    help="synthetic = citygen look-alike (fast to build); reference = worldgen, the reference's city for the seed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -106,7 +112,7 @@ def main():
 
     from trafficsimulation_amd._lib import new_engine
     seed = args.seed + 1000 * rank
-    tables, routes, gen_t = make_workload(args.size, args.vehicles, seed)
+    tables, routes, gen_t = make_workload(args.size, args.vehicles, seed, args.world)
     api = new_engine()
     api.set_device(local_rank)
     setup(api, tables, routes, seed, policy=args.policy)
@@ -166,7 +172,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {
-                "workload": f"{args.size}x{args.size} synthetic city (citygen seed {args.seed}), {v0} vehicles per GPU, "
+                "workload": f"{args.size}x{args.size} " + ("synthetic city (citygen" if args.world == "synthetic" else "reference-generated city (worldgen")
+                            + f" seed {args.seed}), {v0} vehicles per GPU, "
                             + ("config-2 policy: car-following + movement kernels, lights DISABLED, replans gated off, "
                                "malfunction/sideswipe chance 0; random-walk routes" if args.policy == "config2" else
                                "lights policy: config 2 plus QUEUE_ACTUATED light groups (phase change, intersection "

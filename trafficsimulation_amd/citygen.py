@@ -1,7 +1,7 @@
 """Synthetic, procedurally generated city grids for benchmarks and large-size parity tests.
 
-This is NOT the seed-compatible restatement of the reference's world generator (that is the
-"next" row SURVEY.md §8(f).1; the reference's own generator is superlinear Python: 32 s at 512²).
+This is NOT the seed-compatible restatement of the reference's world generator - that is worldgen.py (exact, but
+interpreted: 4 s at 512², minutes at 4096²; the reference's own generator takes 32 s at 512²).
 It produces worlds with the same *structure* the hot path consumes, following the reference's
 layout rules at band granularity:
 
@@ -301,6 +301,7 @@ def make_routes(tables: dict, n_vehicles: int, seed: int = 2, min_len: int = 200
         for q in range(4):
             opts[b, q] = ds[q % len(ds)] if ds else 0
     aflat = allowed.ravel()
+    drivable = (tables["is_road_map"].ravel() == 1) | (aflat != 0)
     step = np.array([W, 1, -W, -1])
     for t in range(L):
         bits = aflat[pos].astype(np.int64)
@@ -319,7 +320,8 @@ def make_routes(tables: dict, n_vehicles: int, seed: int = 2, min_len: int = 200
         nx, ny = x + DX[d], y + DY[d]
         inb = (nx >= 0) & (nx < W) & (ny >= 0) & (ny < H)
         ok &= inb
-        ok &= (tables["is_road_map"].ravel()[np.where(inb, npos, 0)] == 1)
+        # drivable = road-like or carrying arrows (the reference's ControlledRoad cells have arrows but is_road_map 0)
+        ok &= drivable[np.where(inb, npos, 0)]
         dirs[ok, t] = d[ok]
         pos = np.where(ok, npos, pos)
         heading = np.where(ok, d, heading)
