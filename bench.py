@@ -196,7 +196,7 @@ def main():
             },
             "kernels_ms_per_tick": {k: v[0] / args.steps for k, v in prof.items() if not k.startswith("host_")},
             "host_ms_per_tick": {k: prof[k][0] / args.steps for k in host_keys},
-            "setup_seconds": {"citygen": gen_t[0], "routes": gen_t[1]},
+            "setup_seconds": {"world": gen_t[0], "routes": gen_t[1]},
         }
     api.close()
 
