@@ -191,9 +191,10 @@ class WorldBuilder:
                         self.place(x, y, SIDEWALK)
 
     def clear_interior(self):
+        n = self.x_max - self.x_min + 1           # nothing but Wall / Sidewalk so far: only the type changes
         for y in range(self.y_min, self.y_max + 1):
-            for x in range(self.x_min, self.x_max + 1):
-                self.place(x, y, NOTHING)
+            a = self.idx(self.x_min, y)
+            self.ct[a:a + n] = [NOTHING] * n
 
     # ---- bands (city_model.py:1076-1267) ----
     def choose_road_type(self):
@@ -354,9 +355,10 @@ class WorldBuilder:
             in_ring_rows = lambda y: (self.y_min <= y < self.y_min + ft) or (self.y_max - ft + 1 <= y <= self.y_max)
             in_ring_cols = lambda x: (self.x_min <= x < self.x_min + ft) or (self.x_max - ft + 1 <= x <= self.x_max)
         vcover = [self.band_covering(x, self.v_bands) for x in range(w)]
+        vcols = [x for x in range(w) if vcover[x]]
         for y in range(h):
             hb = self.band_covering(y, self.h_bands)
-            for x in range(w):
+            for x in (range(w) if hb else vcols):
                 vb = vcover[x]
                 if hb and vb:
                     if (hb[2] != R1 or vb[2] != R1) and not self.inside_interior(x, y):
@@ -509,19 +511,21 @@ class WorldBuilder:
     # ---- blocks (city_model.py:742-806) ----
     def flood_fill_blocks(self):
         visited = set()
+        ct, W = self.ct, self.W
         for y in range(self.H):
-            for x in range(self.W):
-                if (x, y) in visited or self.ct[self.idx(x, y)] != NOTHING:
+            row = y * W
+            for x in range(W):
+                if ct[row + x] != NOTHING:        # (a visited cell already carries its block type)
                     continue
                 stack, region = [(x, y)], []
                 while stack:
                     cx, cy = stack.pop()
-                    if (cx, cy) in visited or self.ct[self.idx(cx, cy)] != NOTHING:
+                    if (cx, cy) in visited or ct[cy * W + cx] != NOTHING:
                         continue
                     visited.add((cx, cy))
                     region.append((cx, cy))
                     for nx, ny in ((cx + 1, cy), (cx - 1, cy), (cx, cy + 1), (cx, cy - 1)):
-                        if self.inb(nx, ny) and (nx, ny) not in visited and self.ct[self.idx(nx, ny)] == NOTHING:
+                        if self.inb(nx, ny) and (nx, ny) not in visited and ct[ny * W + nx] == NOTHING:
                             stack.append((nx, ny))
                 if not region:
                     continue
@@ -549,9 +553,11 @@ class WorldBuilder:
         changed = True
         while changed:
             changed = False
+            ct, W = self.ct, self.W
             for y in range(self.H):
-                for x in range(self.W):
-                    if self.ct[self.idx(x, y)] in REMOVABLE_DEAD_END:
+                row = y * W
+                for x in range(W):
+                    if ct[row + x] in REMOVABLE_DEAD_END:
                         k = sum(1 for dx, dy in NB4 if self.type_at(x + dx, y + dy) in ROAD_LIKE)
                         if k < 2:
                             self.place(x, y, SIDEWALK)
@@ -652,6 +658,9 @@ class WorldBuilder:
         """CellAgent.leads_to (cell.py:200-226): is dst reachable from src along the arrows"""
         if src == dst:
             return True
+        for d in self.dirs[src[1] * self.W + src[0]]:     # the usual case: the very next cell
+            if (src[0] + VEC[d][0], src[1] + VEC[d][1]) == dst:
+                return True
         seen = {src}
         frontier = [src]
         while frontier:
@@ -818,16 +827,17 @@ class WorldBuilder:
             for dx, dy in ((1, 1), (1, -1), (-1, 1), (-1, -1)):
                 if self.type_at(lx + dx, ly + dy) == INTERSECTION:
                     starts.append((lx + dx, ly + dy))
+        ct, grp, Wd, Ht = self.ct, self.group, self.W, self.H
         for cx, cy in starts:
             for d in ALL_DIRS:
                 x, y, steps = cx, cy, 0
                 dx, dy = VEC[d]
                 while steps < max_depth:
                     x, y = x + dx, y + dy
-                    if not self.inb(x, y):
+                    if not (0 <= x < Wd and 0 <= y < Ht):
                         break
-                    i = self.idx(x, y)
-                    og = self.group[i] if self.ct[i] == INTERSECTION else None
+                    i = y * Wd + x
+                    og = grp[i] if ct[i] == INTERSECTION else None
                     if og is None or og is g:
                         steps += 1
                         continue
@@ -978,4 +988,11 @@ def generate_world(width=200, height=200, seed=None, **options) -> dict:
 
     `options` are the reference constructor's keyword arguments (city_model.py:27-53) plus the `Defaults` switches that
     reach the tables: `block_entrance_road_level`, `rain_enabled`, `enable_traffic`."""
-    return WorldBuilder(width, height, seed=seed, **options).build().tables()
+    import gc
+    was_enabled = gc.isenabled()
+    gc.disable()          # millions of small tracked objects and no garbage: the cyclic collector only costs (1.6x at 1024^2)
+    try:
+        return WorldBuilder(width, height, seed=seed, **options).build().tables()
+    finally:
+        if was_enabled:
+            gc.enable()
