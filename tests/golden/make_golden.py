@@ -184,6 +184,9 @@ def world_tables(m):
             nb_ctor[i, k] = (DIRI[d], gidx.get(id(ng), -1))
         assert g.opposite_pairs == {"N-S": [], "W-E": []}, g.opposite_pairs
     out["g_neighbors_ctor"] = nb_ctor
+    # intermediate_groups: a set of agents (iteration order carries no meaning) -> ascending group indices
+    out["g_intermediate_ctor_off"], out["g_intermediate_ctor"] = ragged(
+        [sorted(gidx[id(x)] for x in (g.intermediate_groups or ())) for g in groups], 1)
     saved = [(g.neighbor_groups, g.intermediate_groups, g.opposite_pairs) for g in groups]
     for g in groups:
         g.populate_links()
@@ -196,6 +199,8 @@ def world_tables(m):
         for k, (d, ng) in enumerate((g.neighbor_groups or {}).items()):
             nb[i, k] = (DIRI[d], gidx.get(id(ng), -1))
     out["g_neighbors"] = nb
+    out["g_intermediate_off"], out["g_intermediate"] = ragged(
+        [sorted(gidx[id(x)] for x in (g.intermediate_groups or ())) for g in groups], 1)
     for g, (a, b, c) in zip(groups, saved):
         g.neighbor_groups, g.intermediate_groups, g.opposite_pairs = a, b, c
     out["g_icell_off"], out["g_icell_xy"] = ragged(

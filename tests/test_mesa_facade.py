@@ -205,3 +205,22 @@ def test_facade_builds_reference_world_from_seed(oracle):
         assert [v._spawn_idx for v in m.active_vehicle_agents] == list(want[:, 0])
         assert np.array_equal(m.occupancy_map, np.unpackbits(tr["occ_t"][t])[:H * W].reshape(H, W))
         assert np.array_equal(m.rain_map, np.unpackbits(tr["rain_t"][t])[:H * W].reshape(H, W))
+
+
+def test_facade_intermediate_group_handlers_over_oracle(oracle):
+    """/set_group_neighbors_intermediate_stop|go (traffic_light_control.py:389-399) on a worldgen city whose light
+    groups have intermediate groups (ring road R3, seed 103: the reference's tables are in worlds.npz)."""
+    m = CityModel(96, 96, seed=103, ring_road_type="R3", defaults={"RAIN_ENABLED": False}, engine=oracle)
+    with_mid = [g for g in m.intersection_light_groups if g.get_intermediate_groups()]
+    assert with_mid, "this world is expected to have intermediate groups in its constructor-time links"
+    g = with_mid[0]
+    involved = [g] + list(g.get_neighbor_groups().values()) + g.get_intermediate_groups()
+    g.set_all_stop_with_neighbors_and_intermediate()
+    for grp in involved:
+        for tl in grp.traffic_lights:
+            assert m.stop_map[tl.position[1], tl.position[0]] == 1
+    g.set_all_go_with_neighbors_and_intermediate()
+    for grp in involved:
+        for tl in grp.traffic_lights:
+            assert m.stop_map[tl.position[1], tl.position[0]] == 0
+    m.step()

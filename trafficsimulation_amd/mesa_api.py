@@ -430,7 +430,25 @@ class IntersectionLightGroup:
         return {DIR_NAMES[int(d)]: m.intersection_light_groups[int(g)] for d, g in nb if d >= 0 and g >= 0}
 
     def get_intermediate_groups(self):
-        raise NotImplementedError("intermediate groups are not part of the light tables (no controller reads them)")
+        """Groups lying between this one and a neighbour without closing all lanes (the reference keeps a set; a list in
+        ascending group order here).  Needs the `g_intermediate*` tables (worldgen and make_golden's `worlds` job write
+        them; trace fixtures captured earlier do not hold them)."""
+        m = self.model
+        key = "g_intermediate" if m.engine.group_links(self.index, False) else "g_intermediate_ctor"
+        if key not in m.tables:
+            raise NotImplementedError("these world tables carry no intermediate-group lists")
+        off = np.asarray(m.tables[key + "_off"])
+        return [m.intersection_light_groups[int(g)] for g in np.asarray(m.tables[key])[int(off[self.index]):int(off[self.index + 1])]]
+
+    def set_all_go_with_neighbors_and_intermediate(self):     # 332-337
+        self.set_all_go_with_neighbors()
+        for g in self.get_intermediate_groups():
+            g.set_all_go()
+
+    def set_all_stop_with_neighbors_and_intermediate(self):   # 339-344
+        self.set_all_stop_with_neighbors()
+        for g in self.get_intermediate_groups():
+            g.set_all_stop()
 
     def set_all_go_with_neighbors(self):      # 322-325
         self.set_all_go()

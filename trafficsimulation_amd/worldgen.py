@@ -58,13 +58,15 @@ class _Light:
 
 
 class _Group:
-    __slots__ = ("lights", "cells", "neighbors", "ctor_neighbors", "blocks_cache", "ns_in", "ns_out", "ew_in", "ew_out", "ns_lights", "ew_lights")
+    __slots__ = ("lights", "cells", "neighbors", "ctor_neighbors", "intermediate", "ctor_intermediate", "blocks_cache", "ns_in", "ns_out", "ew_in", "ew_out", "ns_lights", "ew_lights")
 
     def __init__(self, lights, cells):
         self.lights: List[_Light] = lights
         self.cells: List[Tuple[int, int]] = cells
         self.neighbors: Dict[int, "_Group"] = {}
         self.ctor_neighbors: Dict[int, "_Group"] = {}
+        self.intermediate: List["_Group"] = []        # intermediate_groups: groups passed over on the way to a neighbour
+        self.ctor_intermediate: List["_Group"] = []
         self.blocks_cache: Dict[int, bool] = {}       # the reference's sticky `_blocks_<d>` attributes
         self.ns_in, self.ns_out, self.ew_in, self.ew_out = [], [], [], []
         self.ns_lights: List[_Light] = []
@@ -788,6 +790,7 @@ class WorldBuilder:
             g = _Group(lights, [])
             self.populate_links(g)              # inside the constructor: own cells are not tagged yet
             g.ctor_neighbors = dict(g.neighbors)
+            g.ctor_intermediate = list(g.intermediate)
             for tl in lights:
                 for (bx, by) in tl.incoming + tl.outgoing:
                     bd = self.dirs[self.idx(bx, by)]
@@ -821,6 +824,7 @@ class WorldBuilder:
 
     def populate_links(self, g: _Group, max_depth=1000):
         g.neighbors = {}
+        g.intermediate = []
         starts = []
         for tl in g.lights:
             lx, ly = tl.pos
@@ -846,6 +850,8 @@ class WorldBuilder:
                     if og.blocks_cache[d]:
                         g.neighbors[d] = og
                         break
+                    if not any(og is o for o in g.intermediate):
+                        g.intermediate.append(og)
                     steps += 1
         axis = {N: [], S: [], E: [], W: []}
         for tl in g.lights:
@@ -957,12 +963,15 @@ class WorldBuilder:
                     nb[i, k] = (d, gidx.get(id(ng), -1))
             return nb
         out["g_neighbors_ctor"] = neighbor_table(lambda g: g.ctor_neighbors)
+        # intermediate_groups is a set of agents in the reference (no order to keep): ascending group indices
+        out["g_intermediate_ctor_off"], out["g_intermediate_ctor"] = ragged([sorted(gidx[id(o)] for o in g.ctor_intermediate) for g in groups], 1)
         # the first phase change re-runs populate_links with every cell tagged: tables as they stand after that
         for g in groups:
             self.populate_links(g)
         out["g_ns_lights_off"], out["g_ns_lights"] = ragged([[lidx[id(tl)] for tl in g.ns_lights] for g in groups], 1)
         out["g_ew_lights_off"], out["g_ew_lights"] = ragged([[lidx[id(tl)] for tl in g.ew_lights] for g in groups], 1)
         out["g_neighbors"] = neighbor_table(lambda g: g.neighbors)
+        out["g_intermediate_off"], out["g_intermediate"] = ragged([sorted(gidx[id(o)] for o in g.intermediate) for g in groups], 1)
         out["g_icell_off"], out["g_icell_xy"] = ragged([[c for p in g.cells for c in p] for g in groups], 2)
         for nm in ("ns_in", "ns_out", "ew_in", "ew_out"):
             out[f"g_{nm}_off"], out[f"g_{nm}_xy"] = ragged([[c for p in getattr(g, nm) for c in p] for g in groups], 2)
