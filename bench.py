@@ -36,7 +36,7 @@ ALGO_BYTES = {"k_decide_pre": 10, "k_decide_main": 44, "k_move_claim": 0, "k_mov
 
 # "config 2" policy of BASELINE.md: car-following + movement kernels only.  Lights disabled, replans
 # gated off; malfunction / sideswipe chances 0 (their draws are still consumed) because a stranded
-# blocker forces a replan and the GPU A* is not built yet.
+# blocker forces a replan, and replanning (the GPU A*) belongs to config 3 (`--policy full`).
 POLICY = {
     "TRAFFIC_LIGHT_AGENT_ALGORITHM": "DISABLED", "PATHFINDING_COOLDOWN": 10 ** 9,
     "VEHICLE_STUCK_RECOMPUTE_THRESHOLD": 10 ** 9, "VEHICLE_STUCK_RECOMPUTE_THRESHOLD_INTERSECTION": 10 ** 9,
