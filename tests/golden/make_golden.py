@@ -103,6 +103,16 @@ SCENARIOS = {
                                      "TOTAL_SERVICE_VEHICLES_FOOD": 200, "TOTAL_SERVICE_VEHICLES_WASTE": 200,
                                      "INTERNAL_POPULATION_TRAFFIC_PER_DAY": 6000, "PASSING_POPULATION_TRAFFIC_PER_DAY": 2400},
                            model_kwargs=dict(carve_subblock_roads=True)),
+    # non-square grids with every subsystem on (wide and tall): row-major indexing, rain drift, exits on all four edges
+    "rect_96x64_s18": dict(size=96, height=64, seed=18, vehicles=60, ticks=220,
+                           defaults={"RAIN_RADIUS_MIN": 8, "RAIN_RADIUS_MAX": 20, "RAIN_SPAWN_CHANCE": 0.15,
+                                     "TOTAL_SERVICE_VEHICLES_FOOD": 150, "TOTAL_SERVICE_VEHICLES_WASTE": 150,
+                                     "INTERNAL_POPULATION_TRAFFIC_PER_DAY": 8000, "PASSING_POPULATION_TRAFFIC_PER_DAY": 3000}),
+    "rect_64x112_s19": dict(size=64, height=112, seed=19, vehicles=60, ticks=220,
+                            defaults={"RAIN_RADIUS_MIN": 8, "RAIN_RADIUS_MAX": 20, "RAIN_SPAWN_CHANCE": 0.15,
+                                      "TOTAL_SERVICE_VEHICLES_FOOD": 150, "TOTAL_SERVICE_VEHICLES_WASTE": 150,
+                                      "INTERNAL_POPULATION_TRAFFIC_PER_DAY": 8000, "PASSING_POPULATION_TRAFFIC_PER_DAY": 3000},
+                            model_kwargs=dict(carve_subblock_roads=True)),
     # config 1 of BASELINE.json: everything on (rain, traffic generator, service vehicles, city blocks)
     "config1_64_s11": dict(size=64, seed=11, vehicles=50, ticks=500, defaults={}),
 }
@@ -327,7 +337,7 @@ def run_scenario(name):
             pre_day0["st"] = random.getstate()
         return orig_gen(self, day_idx)
     dtg.DynamicTrafficAgent._generate_day = gen_day
-    m = CityModel(width=size, height=size, seed=seed, **spec.get("model_kwargs", {}))
+    m = CityModel(width=size, height=spec.get("height", size), seed=seed, **spec.get("model_kwargs", {}))
     if "st" in pre_day0:
         pre = pre_day0["st"][1]
     else:

@@ -14,7 +14,7 @@ from tests.trace_util import trace_path
 
 pytestmark = pytest.mark.gpu
 
-WORLDS = ["service_64_s15", "service_heavy_96_s16", "config5_96_s17", "config1_64_s11"]
+WORLDS = ["service_64_s15", "service_heavy_96_s16", "config5_96_s17", "config1_64_s11", "rect_96x64_s18", "rect_64x112_s19"]
 
 
 def random_case(case: int):

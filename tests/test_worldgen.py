@@ -50,7 +50,7 @@ def test_world_matches_reference(entry):
 def test_trace_world_matches_reference(path):
     tr = load_trace(path)
     sc = tr["scenario"]
-    w = generate_world(sc["size"], sc["size"], seed=sc["seed"], **_options(sc.get("model_kwargs", {}), tr["defaults_json"]))
+    w = generate_world(sc["size"], sc.get("height", sc["size"]), seed=sc["seed"], **_options(sc.get("model_kwargs", {}), tr["defaults_json"]))
     for k in sorted(w):
         if k == "global_rng_state":
             if "global_rng_before_day0" in tr:     # state when DynamicTrafficAgent draws day 0 = right after world-gen
@@ -62,7 +62,7 @@ def test_trace_world_matches_reference(path):
 def _seed_only(tr):
     """The fixture with every world table, and both stream states, replaced by what (size, seed) alone yields."""
     sc = tr["scenario"]
-    w = generate_world(sc["size"], sc["size"], seed=sc["seed"], **_options(sc.get("model_kwargs", {}), tr["defaults_json"]))
+    w = generate_world(sc["size"], sc.get("height", sc["size"]), seed=sc["seed"], **_options(sc.get("model_kwargs", {}), tr["defaults_json"]))
     out = dict(tr)
     for k, v in w.items():
         if k != "global_rng_state":

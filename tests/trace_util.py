@@ -24,6 +24,7 @@ def trace_path(name):
 DTA_TRACES = ["dta_64_s12", "dta_96_s13"]
 RAIN_TRACES = ["rain_96_s14"]
 SERVICE_TRACES = ["service_64_s15", "service_heavy_96_s16", "config1_64_s11", "config5_96_s17"]
+RECT_TRACES = ["rect_96x64_s18", "rect_64x112_s19"]   # non-square grids, every subsystem on
 
 
 def setup_from_trace(api, tr, explicit_paths=False):
