@@ -113,6 +113,8 @@ SCENARIOS = {
                                       "TOTAL_SERVICE_VEHICLES_FOOD": 150, "TOTAL_SERVICE_VEHICLES_WASTE": 150,
                                       "INTERNAL_POPULATION_TRAFFIC_PER_DAY": 8000, "PASSING_POPULATION_TRAFFIC_PER_DAY": 3000},
                             model_kwargs=dict(carve_subblock_roads=True)),
+    # the reference exactly as it ships: CityModel() at its default 200 x 200 with config.py untouched
+    "default_200_s20": dict(size=200, seed=20, vehicles=120, ticks=160, defaults={}),
     # config 1 of BASELINE.json: everything on (rain, traffic generator, service vehicles, city blocks)
     "config1_64_s11": dict(size=64, seed=11, vehicles=50, ticks=500, defaults={}),
 }

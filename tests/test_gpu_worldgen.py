@@ -17,7 +17,7 @@ def hip():
     api.close()
 
 
-@pytest.mark.parametrize("name,ticks", [("config1_64_s11", 300), ("config5_96_s17", 150), ("rain_96_s14", 120), ("rect_96x64_s18", 150)])
+@pytest.mark.parametrize("name,ticks", [("config1_64_s11", 300), ("config5_96_s17", 150), ("rain_96_s14", 120), ("rect_96x64_s18", 150), ("default_200_s20", 160)])
 def test_seed_only_run_reproduces_reference_trace(hip, name, ticks):
     tr = _seed_only(load_trace(trace_path(name)))
     setup_from_trace(hip, tr)

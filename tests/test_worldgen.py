@@ -72,7 +72,7 @@ def _seed_only(tr):
     return out
 
 
-@pytest.mark.parametrize("name,ticks", [("config1_64_s11", 200), ("service_64_s15", 120)])
+@pytest.mark.parametrize("name,ticks", [("config1_64_s11", 200), ("service_64_s15", 120), ("default_200_s20", 160)])
 def test_seed_only_run_reproduces_reference_trace(oracle, name, ticks):
     """size + seed -> world-gen -> engine (the CPU oracle here; tests/test_gpu_worldgen.py runs the HIP engine):
     the per-tick trace of the reference's own CityModel(width, height, seed=seed) run."""

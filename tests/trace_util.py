@@ -25,6 +25,7 @@ DTA_TRACES = ["dta_64_s12", "dta_96_s13"]
 RAIN_TRACES = ["rain_96_s14"]
 SERVICE_TRACES = ["service_64_s15", "service_heavy_96_s16", "config1_64_s11", "config5_96_s17"]
 RECT_TRACES = ["rect_96x64_s18", "rect_64x112_s19"]   # non-square grids, every subsystem on
+DEFAULT_TRACES = ["default_200_s20"]                   # CityModel() as the reference ships: 200 x 200, config.py untouched
 
 
 def setup_from_trace(api, tr, explicit_paths=False):
