@@ -394,6 +394,8 @@ def run_scenario(name):
     vehicles = []
     for i, (sx, sy) in enumerate(starts):
         goal = prng.choice(exits)
+        while goal.get_position() == (sx, sy):   # a trip that ends where it starts despawns inside the decide phase, which
+            goal = prng.choice(exits)            # the engine refuses by contract (TS_E_UNSUPPORTED): draw another exit
         start_cell = m.get_cell_contents(sx, sy)[0]
         v = VehicleAgent(f"gv_{i}", m, start_cell, goal, population_type="through")
         v._g_idx = i
