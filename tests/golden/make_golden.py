@@ -158,6 +158,17 @@ def world_tables(m):
         road_type_map=m.road_type_map.copy(), intersection_map=m.intersection_map.copy(),
         stop_map0=m.stop_map.copy(),
     )
+    # what the portrayal layer reads per cell: CellAgent.cell_type (as an index into this list) and .block_id (0 = None)
+    names = ["Wall", "Sidewalk", "Nothing", "R1", "R2", "R3", "Intersection", "BlockEntrance", "HighwayEntrance",
+             "HighwayExit", "ControlledRoad", "TrafficLight", "Residential", "Office", "Market", "Leisure", "Other", "Empty"]
+    ctm = np.zeros((m.height, m.width), dtype=np.int8)
+    bim = np.zeros((m.height, m.width), dtype=np.int32)
+    for y in range(m.height):
+        for x in range(m.width):
+            c = m.get_cell_contents(x, y)[0]
+            ctm[y, x] = names.index(c.cell_type)
+            bim[y, x] = c.block_id or 0
+    out["cell_type_map"], out["block_id_map"] = ctm, bim
     groups = m.intersection_light_groups
     gidx = {id(g): i for i, g in enumerate(groups)}
     # ragged tables: (offsets[G+1], flat values)
@@ -240,6 +251,7 @@ def world_tables(m):
     # Defaults.AVAILABLE_CITY_BLOCKS and the entrance cells of each block (CityBlock.get_entrances())
     blocks = list(getattr(m, "city_blocks", {}).values())
     types = list(Defaults_AVAILABLE)
+    out["blk_id"] = np.asarray(list(getattr(m, "city_blocks", {}).keys()), dtype=np.int32)
     out["blk_type"] = np.asarray([types.index(b.block_type) for b in blocks], dtype=np.int32)
     out["blk_entr_off"], out["blk_entr_xy"] = ragged([[c for e in b.get_entrances() for c in e.position] for b in blocks], 2)
     out["blk_inner_cells"] = np.asarray([len(b.get_inner_blocks()) for b in blocks], dtype=np.int32)

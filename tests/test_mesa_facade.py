@@ -224,3 +224,39 @@ def test_facade_intermediate_group_handlers_over_oracle(oracle):
         for tl in grp.traffic_lights:
             assert m.stop_map[tl.position[1], tl.position[0]] == 0
     m.step()
+
+
+def test_facade_cell_types_blocks_and_block_queries_over_oracle(oracle):
+    """Worlds from worldgen carry the reference's cell_type / block_id per cell (pinned by worlds.npz), so the facade's
+    cells report them like CellAgent does, `city_blocks` is keyed by block_id, and the block pickers of
+    city_model.py:2017-2087 work on the engine's block stock."""
+    import json
+    tr = load_trace(trace_path("config1_64_s11"))
+    m = CityModel(64, 64, seed=11, defaults=tr["defaults_json"], engine=oracle, traffic=json.loads(str(tr["dta_params"])))
+    assert m.cell(0, 0).cell_type == "Wall" and m.cell(0, 0).block_id is None
+    for be in m.block_entrances:
+        assert be.cell_type == "BlockEntrance" and be.block_id in m.city_blocks
+        assert be.block_type == m.city_blocks[be.block_id].block_type
+        assert be.get_portrayal()["Block ID"] == be.block_id and be.get_portrayal()["Color"] == "magenta"
+        assert be in m.city_blocks[be.block_id].get_entrances()
+    assert {c.cell_type for c in m.highway_entrances} == {"HighwayEntrance"}
+    assert {c.cell_type for c in m.highway_exits} == {"HighwayExit"}
+    assert {c.cell_type for c in m.controlled_roads} == {"ControlledRoad"}
+    kinds = {m.cell(x, y).cell_type for y in range(64) for x in range(64)}
+    assert {"Sidewalk", "R2", "Intersection", "TrafficLight"} <= kinds
+    assert m.is_type(0, 0, "Wall") and not m.is_type(-1, 0, "Wall") and m.next_cell_in_direction(3, 4, "N") == (3, 5)
+    assert list(m.city_blocks) == [b.block_id for b in m.get_all_city_blocks()]
+    for _ in range(40):
+        m.step()
+    by_food = m.get_blocks_needing_food(sort_by="food")
+    assert [b.get_food_units() for b in by_food] == sorted(b.get_food_units() for b in by_food)
+    assert all(b.block_type in ("Market", "Leisure") for b in by_food)
+    by_waste = m.get_all_city_blocks(sort_by="waste")
+    assert [b.get_waste_units() for b in by_waste] == sorted((b.get_waste_units() for b in by_waste), reverse=True)
+    assert m.get_block_most_in_need_of_waste_pickup() is by_waste[0]
+    assert m.get_block_most_in_need_of_food() is (by_food[0] if by_food else None)
+    typed = m.get_residential_city_blocks() + m.get_office_city_blocks() + m.get_market_city_blocks() \
+        + m.get_leisure_city_blocks() + m.get_other_city_blocks()
+    assert sorted(b.block_id for b in typed) == sorted(m.city_blocks)
+    assert m.get_city_blocks_by_type("Office") == m.get_city_blocks_by_types(["Office"])
+    assert m.get_city_blocks_by_types(None) == m.get_all_city_blocks()

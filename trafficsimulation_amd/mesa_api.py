@@ -56,7 +56,15 @@ class Defaults:
     AVAILABLE_CITY_BLOCKS = ["Residential", "Office", "Market", "Leisure", "Other"]
     AGENT_PORTRAYAL_LEVEL = 2
     ZONE_COLORS = {"Road": "saddlebrown", "Intersection": "yellow", "Nothing": "white", "TrafficLight": "lime",
-                   "TrafficLightStop": "red", "ControlledRoad": "thistle", "ControlledRoadStop": "salmon"}
+                   "TrafficLightStop": "red", "ControlledRoad": "thistle", "ControlledRoadStop": "salmon",
+                   # config.py:98-120, for worlds whose tables carry `cell_type_map` (worldgen)
+                   "Residential": "cadetblue", "Office": "orange", "Market": "green", "Leisure": "palevioletred",
+                   "Other": "darkkhaki", "Empty": "papayawhip", "Sidewalk": "grey", "Wall": "black", "R1": "dodgerblue",
+                   "R2": "saddlebrown", "R3": "darkgreen", "IntersectionPending": "darkkhaki", "HighwayEntrance": "blue",
+                   "HighwayExit": "royalblue", "BlockEntrance": "magenta"}
+
+
+from .worldgen import CELL_TYPE_NAMES as _CELL_TYPE_NAMES
 
 
 class CellAgent:
@@ -75,6 +83,8 @@ class CellAgent:
     def cell_type(self) -> str:
         x, y = self.position
         m = self.model
+        if m._cell_type_map is not None:          # the reference's own type strings (worldgen tables)
+            return _CELL_TYPE_NAMES[int(m._cell_type_map[y, x])]
         if (x, y) in m._light_index:
             return "TrafficLight"
         if m.intersection_map[y, x]:
@@ -82,6 +92,24 @@ class CellAgent:
         if (x, y) in m._controlled_cells:
             return "ControlledRoad"
         return "Road" if m.is_road_map[y, x] else "Nothing"
+
+    @property
+    def block_id(self):
+        """CellAgent.block_id of block cells and block entrances (None elsewhere, or without a `block_id_map` table)."""
+        m = self.model
+        b = int(m._block_id_map[self.position[1], self.position[0]]) if m._block_id_map is not None else 0
+        return b or None
+
+    @property
+    def block_type(self):
+        b = self.block_id
+        blk = self.model.city_blocks.get(b) if b else None
+        return blk.block_type if blk is not None else None
+
+    @property
+    def road_type(self):
+        ct = self.cell_type
+        return ct if ct in ("R1", "R2", "R3") else None
 
     @property
     def directions(self) -> List[str]:
@@ -113,6 +141,8 @@ class CellAgent:
         p = {"Shape": "rect", "w": 1.0, "h": 1.0, "Filled": True, "Layer": 0, "Color": color, "Position": self.position}
         if ct == "ControlledRoad":
             p["Control State"] = "Stop" if is_stop else "Go"
+        if self.block_id is not None:               # cell.py:316-317
+            p["Block ID"] = self.block_id
         arrows = [DIRECTION_ICONS[d] for d in self.directions]
         if arrows:
             p["Directions"] = " ".join(arrows)
@@ -341,10 +371,11 @@ class ServiceVehicleAgent(VehicleAgent):
 class CityBlock:
     """View of a CityBlock (city_block.py:14-150): stock lives in the engine."""
 
-    def __init__(self, model: "CityModel", index: int, block_type: str, inner_cells: int, entrances):
+    def __init__(self, model: "CityModel", index: int, block_type: str, inner_cells: int, entrances, block_id=None):
         self.model = self.city_model = model
         self.index = index
-        self.id = f"Block_{index + 1}"
+        self.block_id = int(block_id) if block_id is not None else index + 1   # key in model.city_blocks (city_model.py:1743)
+        self.id = f"CB_{self.block_id}"                                          # custom_id of _spawn_city_block (1729)
         self.unique_id = str_to_unique_int(self.id)
         self.block_type = block_type
         self._n_inner = int(inner_cells)
@@ -600,6 +631,8 @@ class CityModel:
         self.is_road_map = np.asarray(tables["is_road_map"], dtype=np.int8)
         self.road_type_map = np.asarray(tables["road_type_map"], dtype=np.int8)
         self.intersection_map = np.asarray(tables["intersection_map"], dtype=np.int8)
+        self._cell_type_map = np.asarray(tables["cell_type_map"]) if "cell_type_map" in tables else None
+        self._block_id_map = np.asarray(tables["block_id_map"]) if "block_id_map" in tables else None
         self._stop_host = np.zeros((self.height, self.width), dtype=np.int8)
         self._stop_dirty = False
         self.step_count = 0
@@ -643,10 +676,11 @@ class CityModel:
         if "blk_type" in tables and 1 in np.asarray(tables["schedule_kinds0"]):
             eoff, exy = np.asarray(tables["blk_entr_off"]), np.asarray(tables["blk_entr_xy"]).reshape(-1, 2)
             inner = np.asarray(tables.get("blk_inner_cells", np.zeros(len(eoff) - 1)))
+            ids = np.asarray(tables["blk_id"]) if "blk_id" in tables else np.arange(1, len(eoff))
             for b, t in enumerate(np.asarray(tables["blk_type"])):
                 cb = CityBlock(self, b, Defaults.AVAILABLE_CITY_BLOCKS[int(t)], int(inner[b]),
-                               [self.cell(int(x), int(y)) for x, y in exy[eoff[b]:eoff[b + 1]]])
-                self.city_blocks[cb.id] = cb
+                               [self.cell(int(x), int(y)) for x, y in exy[eoff[b]:eoff[b + 1]]], block_id=int(ids[b]))
+                self.city_blocks[cb.block_id] = cb       # keyed by block_id like the reference's dict
         self.block_entrances = [self.cell(int(x), int(y)) for x, y in np.asarray(tables.get("block_entrances_xy", np.zeros((0, 2)))).reshape(-1, 2)]
         self.highway_entrances = [self.cell(int(x), int(y)) for x, y in np.asarray(tables.get("highway_entrances_xy", np.zeros((0, 2)))).reshape(-1, 2)]
         self.highway_exits = [self.cell(int(x), int(y)) for x, y in np.asarray(tables.get("highway_exits_xy", np.zeros((0, 2)))).reshape(-1, 2)]
@@ -825,6 +859,66 @@ class CityModel:
         if entry_cell in self.block_entrances:
             return [be for be in self.block_entrances if be is not entry_cell] + list(self.highway_exits)
         return []
+
+    # ---- city-block queries (city_model.py:2017-2087): views over the engine's block stock -------------------------
+    @staticmethod
+    def _sort_blocks(blocks, by):
+        if by == "food":
+            return sorted(blocks, key=lambda b: b.get_food_units())
+        if by == "waste":
+            return sorted(blocks, key=lambda b: -b.get_waste_units())
+        return blocks
+
+    def get_all_city_blocks(self, sort_by="unsorted"):
+        return self._sort_blocks(list(self.city_blocks.values()), sort_by)
+
+    def get_blocks_needing_food(self, sort_by="unsorted"):
+        return self._sort_blocks([b for b in self.city_blocks.values() if b.needs_food()], sort_by)
+
+    def get_blocks_producing_waste(self, sort_by="unsorted"):
+        return self._sort_blocks([b for b in self.city_blocks.values() if b.produces_waste()], sort_by)
+
+    def get_city_blocks_by_types(self, block_types, sort_by="unsorted"):
+        if block_types is None:
+            subset = list(self.city_blocks.values())
+        else:
+            wanted = {block_types} if isinstance(block_types, str) else set(block_types)
+            subset = [b for b in self.city_blocks.values() if b.block_type in wanted]
+        return self._sort_blocks(subset, sort_by)
+
+    def get_city_blocks_by_type(self, block_type, sort_by="unsorted"):
+        return self.get_city_blocks_by_types([block_type], sort_by)
+
+    def get_residential_city_blocks(self, sort_by="unsorted"):
+        return self.get_city_blocks_by_types("Residential", sort_by)
+
+    def get_office_city_blocks(self, sort_by="unsorted"):
+        return self.get_city_blocks_by_types("Office", sort_by)
+
+    def get_market_city_blocks(self, sort_by="unsorted"):
+        return self.get_city_blocks_by_types("Market", sort_by)
+
+    def get_leisure_city_blocks(self, sort_by="unsorted"):
+        return self.get_city_blocks_by_types("Leisure", sort_by)
+
+    def get_other_city_blocks(self, sort_by="unsorted"):
+        return self.get_city_blocks_by_types("Other", sort_by)
+
+    def get_block_most_in_need_of_food(self):
+        needy = self.get_blocks_needing_food(sort_by="food")
+        return needy[0] if needy else None
+
+    def get_block_most_in_need_of_waste_pickup(self):
+        dirty = self.get_blocks_producing_waste(sort_by="waste")
+        return dirty[0] if dirty else None
+
+    def is_type(self, x, y, ctype):       # city_model.py:1803-1805
+        return self.in_bounds(x, y) and self.cell(x, y).cell_type == ctype
+
+    @staticmethod
+    def next_cell_in_direction(x, y, d):  # city_model.py:1015-1024
+        dx, dy = {"N": (0, 1), "S": (0, -1), "E": (1, 0), "W": (-1, 0)}.get(d, (0, 0))
+        return x + dx, y + dy
 
     def set_traffic_lights_go(self):      # city_model.py:1995-1997
         for tl in self.traffic_lights:

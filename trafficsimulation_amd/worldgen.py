@@ -28,6 +28,10 @@ EMPTY_BLOCK = BLOCK0 + 5          # "Empty"
 N_BLOCK_TYPES = 5
 BLOCK_WEIGHTS = [0.25, 0.25, 0.2, 0.2, 0.1]   # config.py:53-60 CITY_BLOCK_CHANCE in AVAILABLE_CITY_BLOCKS order
 
+CELL_TYPE_NAMES = ("Wall", "Sidewalk", "Nothing", "R1", "R2", "R3", "Intersection", "BlockEntrance", "HighwayEntrance",
+                   "HighwayExit", "ControlledRoad", "TrafficLight", "Residential", "Office", "Market", "Leisure", "Other",
+                   "Empty")      # CellAgent.cell_type strings, indexed by the codes above (the `cell_type_map` table)
+
 ROADS = (R1, R2, R3)                                                             # config.py:13
 ROAD_LIKE = frozenset((R1, R2, R3, INTERSECTION, HW_ENTRANCE, HW_EXIT, BLOCK_ENTRANCE))          # config.py:68
 ROAD_LIKE_NO_INTER = frozenset((R1, R2, R3, HW_ENTRANCE, HW_EXIT, BLOCK_ENTRANCE))               # config.py:69
@@ -122,6 +126,7 @@ class WorldBuilder:
         self.road_cells: dict = {}           # _road_cells
         self.blocks_data: List[dict] = []
         self.block_entrances: List[Tuple[int, int]] = []
+        self.entrance_block: Dict[Tuple[int, int], int] = {}    # BlockEntrance cell -> block_id
         self.highway_entrances: List[Tuple[int, int]] = []
         self.highway_exits: List[Tuple[int, int]] = []
         self.groups: List[_Group] = []
@@ -620,6 +625,7 @@ class WorldBuilder:
             cx, cy = run[len(run) // 2]
             self.place(cx, cy, BLOCK_ENTRANCE)
             self.block_entrances.append((cx, cy))
+            self.entrance_block[(cx, cy)] = info["block_id"]
 
     def remove_invalid_intersection_directions(self):
         """city_model.py:969-1012"""
@@ -887,7 +893,7 @@ class WorldBuilder:
                     elif t == BLOCK_ENTRANCE and p not in seen:
                         seen.add(p)
                         entrances.append(p)
-            self.blocks.append(dict(type=info["block_type"] - BLOCK0, inner=len(info["region"]), sidewalks=sidewalks,
+            self.blocks.append(dict(id=info["block_id"], type=info["block_type"] - BLOCK0, inner=len(info["region"]), sidewalks=sidewalks,
                                     entrances=entrances, service=self.ranked_service_cells(sidewalks, entrances)))
 
     def ranked_service_cells(self, sidewalks, entrances):
@@ -934,6 +940,17 @@ class WorldBuilder:
         road_type[(ct == HW_ENTRANCE) | (ct == HW_EXIT) | (ct == BLOCK_ENTRANCE) | (ct == INTERSECTION)] = 1
         out = dict(width=np.int32(W), height=np.int32(H), allowed_dirs_map=allowed, is_road_map=is_road,
                    road_type_map=road_type, intersection_map=inter, stop_map0=np.zeros((H, W), np.int8))
+        # what the portrayal layer shows per cell: CellAgent.cell_type (index into CELL_TYPE_NAMES) and .block_id (0 = none)
+        out["cell_type_map"] = ct.astype(np.int8)
+        block_id = np.zeros((H, W), np.int32)
+        for (x, y), b in self.entrance_block.items():
+            if ct[y, x] == BLOCK_ENTRANCE:
+                block_id[y, x] = b
+        for info in self.blocks_data:
+            if info["block_type"] != EMPTY_BLOCK:
+                for (x, y) in info["region"]:
+                    block_id[y, x] = info["block_id"]
+        out["block_id_map"] = block_id
 
         def ragged(rows, width):
             off, flat = [0], []
@@ -981,6 +998,7 @@ class WorldBuilder:
         if self.enable_traffic:
             kinds.append(3)
         out["schedule_kinds0"] = np.asarray(kinds, np.int8)
+        out["blk_id"] = np.asarray([b["id"] for b in self.blocks], np.int32)       # keys of CityModel.city_blocks
         out["blk_type"] = np.asarray([b["type"] for b in self.blocks], np.int32)
         out["blk_entr_off"], out["blk_entr_xy"] = ragged([[c for p in b["entrances"] for c in p] for b in self.blocks], 2)
         out["blk_inner_cells"] = np.asarray([b["inner"] for b in self.blocks], np.int32)
