@@ -260,3 +260,19 @@ def test_facade_cell_types_blocks_and_block_queries_over_oracle(oracle):
     assert sorted(b.block_id for b in typed) == sorted(m.city_blocks)
     assert m.get_city_blocks_by_type("Office") == m.get_city_blocks_by_types(["Office"])
     assert m.get_city_blocks_by_types(None) == m.get_all_city_blocks()
+
+
+def test_example_runner_over_oracle(oracle):
+    """examples/run_city.py: its traffic constants are config.py's (as recorded in the config-1 fixture), and a short run
+    from (size, seed) alone spawns traffic and reports statistics."""
+    import json
+    from examples import run_city
+    tr = load_trace(trace_path("config1_64_s11"))
+    want = json.loads(str(tr["dta_params"]))
+    want.pop("pending_day0")
+    assert run_city.TRAFFIC == want
+    lines = []
+    m = run_city.run(64, 11, 40, every=20, engine=oracle, out=lines.append)
+    assert len(lines) == 3 and lines[0].startswith("city 64x64 seed 11: 4 light groups, 4 blocks")
+    assert m.step_count == 40 and len(m.active_vehicle_agents) > 0
+    assert np.array_equal(m.allowed_dirs_map, tr["allowed_dirs_map"])
