@@ -113,6 +113,17 @@ SCENARIOS = {
                                       "TOTAL_SERVICE_VEHICLES_FOOD": 150, "TOTAL_SERVICE_VEHICLES_WASTE": 150,
                                       "INTERNAL_POPULATION_TRAFFIC_PER_DAY": 8000, "PASSING_POPULATION_TRAFFIC_PER_DAY": 3000},
                             model_kwargs=dict(carve_subblock_roads=True)),
+    # constructor variants of the world under a live run (every subsystem on): full-width intersections, a highway ring,
+    # no ring road, forward light ranges feeding the neighbour-pressure controller's "out" lanes
+    "unopt_96_s21": dict(size=96, seed=21, vehicles=60, ticks=200, defaults={"TRAFFIC_LIGHT_AGENT_ALGORITHM": "NEIGHBOR_GREEN_WAVE"},
+                         model_kwargs=dict(optimized_intersections=False)),
+    "ring_r1_112_s22": dict(size=112, seed=22, vehicles=60, ticks=200, defaults={}, model_kwargs=dict(ring_road_type="R1")),
+    "noring_96_s23": dict(size=96, seed=23, vehicles=60, ticks=200, defaults={"TRAFFIC_LIGHT_AGENT_ALGORITHM": "FIXED_TIME"},
+                          model_kwargs=dict(ring_road_type=None)),
+    "fwdrange_96_s24": dict(size=96, seed=24, vehicles=60, ticks=200,
+                            defaults={"TRAFFIC_LIGHT_AGENT_ALGORITHM": "NEIGHBOR_PRESSURE_CONTROL"},
+                            model_kwargs=dict(forward_traffic_light_range=True,
+                                              forward_traffic_light_range_intersections="Include in Range")),
     # the reference exactly as it ships: CityModel() at its default 200 x 200 with config.py untouched
     "default_200_s20": dict(size=200, seed=20, vehicles=120, ticks=160, defaults={}),
     # config 1 of BASELINE.json: everything on (rain, traffic generator, service vehicles, city blocks)
