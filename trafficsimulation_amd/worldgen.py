@@ -544,11 +544,13 @@ class WorldBuilder:
                     bt = BLOCK0 + self.rng.choices(range(N_BLOCK_TYPES), weights=BLOCK_WEIGHTS, k=1)[0]
                 for bx, by in region:
                     self.place(bx, by, bt)
-                in_region = set(region)          # membership only
+                # the ring = in-bounds 4-neighbours outside the region.  No other cell of this block type can touch the region
+                # (it would have been part of the same blob), so "outside" is a type test on the plane.
                 ring = set()                     # iteration order reaches the entrance placement below
+                H = self.H
                 for bx, by in region:
                     for nx, ny in ((bx + 1, by), (bx - 1, by), (bx, by + 1), (bx, by - 1)):
-                        if self.inb(nx, ny) and (nx, ny) not in in_region:
+                        if 0 <= nx < W and 0 <= ny < H and ct[ny * W + nx] != bt:
                             ring.add((nx, ny))
                 for sx, sy in ring:
                     if self.ct[self.idx(sx, sy)] == NOTHING:
@@ -883,10 +885,16 @@ class WorldBuilder:
             if info["block_type"] == EMPTY_BLOCK:
                 continue
             sidewalks, entrances, seen = [], [], set()
+            ct, W, H = self.ct, self.W, self.H
             for x, y in set(info["region"]):
                 for dx, dy in NB4:
-                    p = (x + dx, y + dy)
-                    t = self.type_at(*p)
+                    nx, ny = x + dx, y + dy
+                    if not (0 <= nx < W and 0 <= ny < H):
+                        continue
+                    t = ct[ny * W + nx]
+                    if t != SIDEWALK and t != BLOCK_ENTRANCE:
+                        continue
+                    p = (nx, ny)
                     if t == SIDEWALK and p not in seen:
                         seen.add(p)
                         sidewalks.append(p)
