@@ -290,6 +290,12 @@ def world_tables(m):
             return []
         return sorted(candidates, key=lambda rc: min(abs(rc[0] - ex) + abs(rc[1] - ey) for ex, ey in entrance_coords))
     out["blk_service_off"], out["blk_service_xy"] = ragged([[c for rc in ranked_service_cells(b) for c in rc] for b in blocks], 2)
+    # labels of the UI's drop-downs (CellAgent.get_display_name), in the order of the tables they belong to
+    out["display_names"] = np.asarray(json.dumps(dict(
+        lights=[str(tl.get_display_name()) for tl in lights_flat],
+        block_entrances=[str(c.get_display_name()) for c in m.block_entrances],
+        highway_entrances=[str(c.get_display_name()) for c in m.highway_entrances],
+        highway_exits=[str(c.get_display_name()) for c in m.highway_exits])))
     out["block_entrances_xy"] = np.asarray([c.position for c in m.block_entrances], dtype=np.int32).reshape(-1, 2)
     out["highway_entrances_xy"] = np.asarray([c.position for c in m.highway_entrances], dtype=np.int32).reshape(-1, 2)
     out["highway_exits_xy"] = np.asarray([c.position for c in m.highway_exits], dtype=np.int32).reshape(-1, 2)

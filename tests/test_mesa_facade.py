@@ -276,3 +276,24 @@ def test_example_runner_over_oracle(oracle):
     assert len(lines) == 3 and lines[0].startswith("city 64x64 seed 11: 4 light groups, 4 blocks")
     assert m.step_count == 40 and len(m.active_vehicle_agents) > 0
     assert np.array_equal(m.allowed_dirs_map, tr["allowed_dirs_map"])
+
+
+@pytest.mark.parametrize("tag", ["rect", "ring_r1", "carve_dense", "seed204"])
+def test_facade_display_names_match_reference(oracle, tag):
+    """CellAgent.get_display_name() - the labels of the UI's light / start / target / entrance drop-downs
+    (ui_modules/*.py) - for every light, block entrance, highway entrance and exit of worlds the reference built."""
+    import json
+    import os
+    from tests.trace_util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "worlds.npz"), allow_pickle=False)
+    e = next(x for x in json.loads(str(z["index"])) if x["tag"] == tag)
+    want = json.loads(str(z[f"{tag}/display_names"]))
+    m = CityModel(e["width"], e["height"], seed=e["seed"], defaults={"RAIN_ENABLED": False}, engine=oracle, **e["kwargs"])
+    assert [str(c.get_display_name()) for c in m.traffic_lights] == want["lights"]
+    assert [str(c.get_display_name()) for c in m.block_entrances] == want["block_entrances"]
+    assert [str(c.get_display_name()) for c in m.highway_entrances] == want["highway_entrances"]
+    assert [str(c.get_display_name()) for c in m.highway_exits] == want["highway_exits"]
+    inter = next(c for g in m.intersection_light_groups for c in g.intersection_cells if c.cell_type == "Intersection")
+    assert inter.get_display_name() == f"Intersection_{inter.position[0]}_{inter.position[1]}"
+    assert m.block_entrances[0].is_block_entrance() and m.highway_exits[0].is_highway_exit()
+    assert m.highway_entrances[0].is_highway_entrance() and m.controlled_roads[0].is_controlled_road()

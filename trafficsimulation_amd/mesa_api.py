@@ -120,6 +120,53 @@ class CellAgent:
     def get_position(self):
         return self.position
 
+    # ---- names and predicates the UI's drop-downs use (cell.py:160-195) -------------------------------------------------
+    def get_display_name(self):
+        ct = self.cell_type
+        x, y = self.position
+        m = self.model
+        if ct == "Intersection":
+            return f"Intersection_{x}_{y}"                      # the custom_id place_cell gave it (city_model.py:240)
+        if ct == "BlockEntrance":
+            return f"BlockEntrance_{self.block_id}"
+        if ct in ("HighwayEntrance", "HighwayExit"):            # _format_highway_label (cell.py:77-156)
+            if y == 0:
+                cardinal = "South"
+            elif y == m.height - 1:
+                cardinal = "North"
+            elif x == 0:
+                cardinal = "West"
+            elif x == m.width - 1:
+                cardinal = "East"
+            else:
+                cardinal = "Center"
+            horizontal = cardinal in ("South", "North")
+            # highway_id is "highway_horizontal" / "highway_vertical" (city_model.py:1413-1416): one id per orientation,
+            # so the label's group index is always 1
+            same = m.highway_entrances if ct == "HighwayEntrance" else m.highway_exits
+            if horizontal:
+                coll = sorted((c for c in same if c.position[1] == y), key=lambda c: c.position[0])
+            else:
+                coll = sorted((c for c in same if c.position[0] == x), key=lambda c: c.position[1])
+            kind = "Entrance" if ct == "HighwayEntrance" else "Exit"
+            return f"{'Horizontal' if horizontal else 'Vertical'}_1_{cardinal}_{kind}_{coll.index(self) + 1}"
+        if ct == "TrafficLight" and self.intersection_group is not None:
+            g = self.intersection_group
+            return f"TrafficLight_I{g.id}_#{g.traffic_lights.index(self)}"
+        return self.position
+
+    def is_block_entrance(self):
+        return self.cell_type == "BlockEntrance"
+
+    def is_highway_entrance(self):
+        return self.cell_type == "HighwayEntrance"
+
+    def is_highway_exit(self):
+        return self.cell_type == "HighwayExit"
+
+    def is_controlled_road(self):
+        return self.cell_type == "ControlledRoad"
+
     def set_light_stop(self):   # cell.py:241-245
         self.model._write_stop([self.position] + [c.position for c in self.controlled_blocks], 1)
 
