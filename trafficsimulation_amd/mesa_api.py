@@ -643,6 +643,8 @@ class CityModel:
                  sched_state=None, traffic: Optional[dict] = None, world: str = "reference", **world_kwargs):
         import random as _random
         self._seed = seed if seed is not None else _random.random()
+        if traffic is not None and "gradual_city_block_resources" in world_kwargs:   # ctor kwarg -> CityBlock mode (city_model.py:50, 1735)
+            traffic = dict(traffic, gradual=bool(world_kwargs["gradual_city_block_resources"]))
         if tables is None and world == "synthetic":
             from . import citygen
             tables = citygen.generate(width, height, seed=seed if seed is not None else 1, **world_kwargs)

@@ -88,7 +88,8 @@ class WorldBuilder:
                  subblock_road_type="R3", min_subblock_spacing=5, highway_offset_from_edges=7,
                  traffic_light_range=10, forward_traffic_light_range=False,
                  forward_traffic_light_range_intersections="Skip", block_entrance_road_level=0,
-                 use_dummy_agents=False, rain_enabled=True, enable_traffic=True):
+                 use_dummy_agents=False, rain_enabled=True, enable_traffic=True,
+                 gradual_city_block_resources=True, cache_cell_portrayal=True):   # accepted like CityModel's; no effect on the tables
         self.W, self.H = int(width), int(height)
         self.rng = rng if rng is not None else _random.Random(seed)
         self.wall = wall_thickness
