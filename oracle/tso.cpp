@@ -1000,7 +1000,11 @@ void group_step(E* e, int gi) {  // IntersectionLightGroup.step (396-423)
           for (int k = 0; k < 4; k++) {
             if (nd[k] < 0 || ngp[k] < 0) continue;
             const Group& n = e->groups[ngp[k]];
-            if (nd[k] == 0 || nd[k] == 2) ns_p -= n.ns_pressure; else ew_p -= n.ew_pressure;
+            // The pressures feed back between neighbours and grow geometrically.  In the capture harness they are np.int32
+            // scalars (0 + int32 array element) and wrap; spelled out here as unsigned arithmetic.  Under numba the
+            // reference's values are unbounded Python ints from that point on: parity unpinned past the first wrap.
+            if (nd[k] == 0 || nd[k] == 2) ns_p = (int)((unsigned)ns_p - (unsigned)n.ns_pressure);
+            else ew_p = (int)((unsigned)ew_p - (unsigned)n.ew_pressure);
           }
         }
         g.ns_pressure = ns_p; g.ew_pressure = ew_p;
