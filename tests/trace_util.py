@@ -32,7 +32,7 @@ DEFAULT_TRACES = ["default_200_s20"]                   # CityModel() as the refe
 
 def setup_from_trace(api, tr, explicit_paths=False):
     dta = json.loads(str(tr["dta_params"])) if "dta_params" in tr else None
-    if dta and (dta["P_int"] > 0 or dta["P_thr"] > 0):
+    if dta and (dta["P_int"] > 0 or dta["P_thr"] > 0 or dta.get("service_food", 0) > 0 or dta.get("service_waste", 0) > 0):
         # the traffic generator draws its day-0 schedule inside CityModel.__init__: start from the stream state
         # just before that and let the engine generate the same day
         build_engine(api, tr, defaults=tr["defaults_json"], global_state=tr["global_rng_before_day0"],
