@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE))); sys.path.insert(0, HERE)
 case = int(sys.argv[1])
 pr = random.Random(77000 + case)
-size = pr.choice([64, 64, 80, 96])
+size = pr.choice([64, 64, 80, 96]) if case < 300 else pr.choice([112, 128])     # cases >= 300: larger maps, denser traffic
 d = {}
 algo = pr.choice(["QUEUE_ACTUATED", "QUEUE_ACTUATED", "FIXED_TIME", "NEIGHBOR_GREEN_WAVE", "NEIGHBOR_PRESSURE_CONTROL", "DISABLED"])
 d["TRAFFIC_LIGHT_AGENT_ALGORITHM"] = algo
@@ -46,7 +46,8 @@ if pr.random() < 0.3: kw["carve_subblock_roads"] = True; kw["subblock_chance"] =
 if pr.random() < 0.3: kw["ring_road_type"] = pr.choice(["R1", "R3", None])
 if pr.random() < 0.2: kw["optimized_intersections"] = False
 if pr.random() < 0.2: kw["forward_traffic_light_range"] = True; kw["forward_traffic_light_range_intersections"] = pr.choice(["Skip", "Include in Range", "Include as Extra"])
-spec = dict(size=size, seed=300 + case, vehicles=pr.choice([20, 60, 120]), ticks=pr.choice([80, 120, 160]), defaults=d, model_kwargs=kw)
+spec = dict(size=size, seed=300 + case, vehicles=pr.choice([20, 60, 120]) if case < 300 else pr.choice([150, 300]),
+            ticks=pr.choice([80, 120, 160]) if case < 300 else pr.choice([50, 70]), defaults=d, model_kwargs=kw)
 if pr.random() < 0.25: spec["height"] = pr.choice([64, 80, 112])
 import make_golden as mg
 mg._setup_paths()
