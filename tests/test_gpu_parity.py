@@ -7,7 +7,7 @@ import pytest
 
 from trafficsimulation_amd import _capi as capi
 from trafficsimulation_amd.world import load_trace
-from tests.trace_util import CLOSED_TRACES, DEFAULT_TRACES, DTA_TRACES, RAIN_TRACES, RECT_TRACES, SERVICE_TRACES, check_initial, replay_and_compare, setup_from_trace, trace_path
+from tests.trace_util import CLOSED_TRACES, DEFAULT_TRACES, DTA_TRACES, RAIN_TRACES, RECT_TRACES, SERVICE_TRACES, VARIANT_TRACES, check_initial, replay_and_compare, setup_from_trace, trace_path
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +20,7 @@ def hip():
     api.close()
 
 
-@pytest.mark.parametrize("name", CLOSED_TRACES + DTA_TRACES + RAIN_TRACES + SERVICE_TRACES + RECT_TRACES + DEFAULT_TRACES)
+@pytest.mark.parametrize("name", CLOSED_TRACES + DTA_TRACES + RAIN_TRACES + SERVICE_TRACES + RECT_TRACES + DEFAULT_TRACES + VARIANT_TRACES)
 def test_hip_reproduces_reference_trace(hip, name):
     """Every closed-population trace captured from the reference: car-following, the light controllers, the
     full replanning policy (GPU A*, phases 0-4), frequent strandings, sub-block roads, and the traffic generator
@@ -49,6 +49,31 @@ def test_hip_astar_kats(hip, golden_dir, tag):
     for i, (sx, sy, gx, gy, soft, ign, maxs) in enumerate(q):
         got = hip.astar(int(sx), int(sy), int(gx), int(gy), bool(soft), bool(ign), int(maxs))
         assert np.array_equal(got, xy[off[i]:off[i + 1]]), f"query {i}: {q[i]}"
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_pathfinder_operator_signature(golden_dir, tag):
+    """trafficsimulation_amd.pathfinding.astar_hip - the reference's `astar(...)` operator signature
+    (astar_numba.py:243-256) - bound to the HIP library (its default engine factory), on the reference's A* KATs."""
+    from trafficsimulation_amd import pathfinding
+    k = np.load(os.path.join(golden_dir, "astar_kats.npz"))
+    H, W = k[f"{tag}_is_road_map"].shape
+    maps = dict(occupancy_map=k[f"{tag}_occupancy_map"], stop_map=k[f"{tag}_stop_map"], is_road_map=k[f"{tag}_is_road_map"],
+                road_type_map=k[f"{tag}_road_type_map"], allowed_dirs_map=k[f"{tag}_allowed_dirs_map"])
+    q, off, xy = k[f"{tag}_queries"], k[f"{tag}_path_off"], k[f"{tag}_path_xy"]
+    try:
+        for i, (sx, sy, gx, gy, soft, ign, maxs) in enumerate(q[::3]):
+            got = pathfinding.astar_hip(W, H, int(sx), int(sy), int(gx), int(gy), respect_awareness=False, awareness_range=10,
+                                        density_map=k[f"{tag}_density32"], soft_obstacles=bool(soft), ignore_flow=bool(ign),
+                                        maximum_steps=int(maxs), **maps)
+            j = 3 * i
+            assert got == [tuple(p) for p in xy[off[j]:off[j + 1]].tolist()], f"query {j}: {q[j]}"
+        assert len(pathfinding._cache) == 1
+        with pytest.raises(capi.EngineError):
+            pathfinding.astar_hip(W, H, 1, 1, 2, 2, respect_awareness=True, awareness_range=10, density_map=None,
+                                  soft_obstacles=False, ignore_flow=False, **maps)
+    finally:
+        pathfinding.release()
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])

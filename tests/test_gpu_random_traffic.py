@@ -128,3 +128,55 @@ def test_hip_vs_oracle_random_traffic(case):
     from oracle import pyoracle
     from trafficsimulation_amd._lib import new_engine
     run_case(case, lambda: (new_engine(), pyoracle.load()), ticks=N_TICKS)
+
+
+def test_schedule_capacity_crossed_mid_tick():
+    """The schedule arrays grow in steps (1024, 3072, ...).  Start just under the first step with an armed traffic
+    generator, so that a spawn inside the move phase pushes the schedule over it while ranks / resolved flags of the
+    agents behind the clock agent are still live (they were regrown without their contents)."""
+    from oracle import pyoracle
+    from trafficsimulation_amd._lib import new_engine
+    tr = load_trace(trace_path("service_heavy_96_s16"))
+    tables = dict(tr)
+    kinds = np.asarray(tables["schedule_kinds0"])
+    tables["schedule_kinds0"] = kinds[kinds != 2]      # no rain manager
+    d = {"RAIN_ENABLED": False, "PATHFINDING_COOLDOWN": 5, "TRAFFIC_LIGHT_AGENT_ALGORITHM": "QUEUE_ACTUATED"}
+    svc = dict(service_food=0, service_waste=0, load_time=2, max_load_food=50.0, max_load_waste=2.5, gradual=True,
+               food_consumption_ticks=50, waste_production_ticks=100, food_capacity_per_cell=2.0, waste_capacity_per_cell=1.5)
+    road = np.asarray(tr["is_road_map"]) == 1
+    inter = np.asarray(tr["intersection_map"]) == 1
+    ys, xs = np.nonzero(road & ~inter)
+    rng = np.random.default_rng(99)
+    apis = (new_engine(), pyoracle.load())
+    n_fixed = len(tables["schedule_kinds0"])
+    n0 = 1024 - n_fixed - 6          # a handful of spawns away from the first capacity step
+    assert n0 > 100
+    pick = rng.choice(len(xs), size=n0, replace=False)
+    starts = np.stack([xs[pick], ys[pick]], axis=1).astype(np.int32)
+    goals_all = np.asarray(tr["v_goal_xy"]).reshape(-1, 2)
+    goals = goals_all[rng.integers(len(goals_all), size=n0)].astype(np.int32)
+    for e in apis:
+        build_engine(e, tables, defaults=d, global_seed=4242, sched_seed=4245)
+        e.set_traffic_generator(tables, internal_per_day=30000, passing_per_day=20000, start_offset_seconds=8 * 3600 - 60,
+                                service=svc)
+        e.add_vehicles(starts, goals, np.full(n0, capi.POP["through"], np.int32))
+    a, b = apis
+    crossed = False
+    for t in range(40):
+        before = a.num_scheduled()
+        a.step(1), b.step(1)
+        ctx = f"tick {t} (scheduled {before} -> {a.num_scheduled()})"
+        va, vb = a.vehicles(), b.vehicles()
+        assert va.shape == vb.shape, f"{ctx}: live vehicles {va.shape} vs {vb.shape}"
+        if not np.array_equal(va, vb):
+            r, col = np.argwhere(va != vb)[0]
+            raise AssertionError(f"{ctx}: vehicle row {r} field {capi.V_FIELDS[col]}: {va[r, col]} vs {vb[r, col]}")
+        for which in (capi.MAP_OCCUPANCY, capi.MAP_STOP, capi.MAP_STUCK):
+            assert np.array_equal(a.map(which), b.map(which)), f"{ctx}: map {which}"
+        assert np.array_equal(a.groups(), b.groups()), f"{ctx}: groups"
+        assert a.rng_fingerprint(capi.RNG_GLOBAL) == b.rng_fingerprint(capi.RNG_GLOBAL), f"{ctx}: global RNG"
+        assert a.num_scheduled() == b.num_scheduled(), f"{ctx}: schedule size"
+        crossed |= a.num_scheduled() > 1024
+    assert crossed, "the run never pushed the schedule past 1024 entries"
+    for e in apis:
+        e.close()

@@ -169,6 +169,13 @@ DEFAULTS_TO_PARAMS = {
     "RAIN_OCCURRENCES_MAX": "rain_occurrences_max", "RAIN_COOLDOWN": "rain_cooldown",
     "RAIN_SPAWN_OFFSET": "rain_spawn_offset", "RAIN_SPAWN_CHANCE": "rain_spawn_chance",
 }
+# switches whose non-default value selects a code path this build does not carry: (unsupported value, why).
+# params_from_defaults refuses them loudly instead of running the default behaviour.
+UNSUPPORTED_DEFAULTS = {
+    "VEHICLE_RESPECT_AWARENESS": (True, "field-of-view masking in A* (astar_numba.py:29-50) is not carried"),
+    "PATHFINDING_BATCHING": (False, "the non-batched step path (vehicle_base.py:666-685) is not carried"),
+    "VEHICLE_STUCK_DESPAWN_ENABLED": (True, "_despawn_check (vehicle_base.py:695-706) is not carried"),
+}
 
 
 class EngineError(RuntimeError):
@@ -253,6 +260,8 @@ class CApi:
         """TsParams from config.py defaults plus `Defaults`-style overrides (UPPER_CASE keys)."""
         p = self.default_params()
         for k, v in (overrides or {}).items():
+            if k in UNSUPPORTED_DEFAULTS and bool(v) == UNSUPPORTED_DEFAULTS[k][0]:
+                raise EngineError(TS_E_UNSUPPORTED, f"{k}={v!r}: {UNSUPPORTED_DEFAULTS[k][1]}")
             if k in DEFAULTS_TO_PARAMS:
                 field = DEFAULTS_TO_PARAMS[k]
                 if field == "light_algorithm":

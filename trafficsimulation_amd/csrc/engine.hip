@@ -217,6 +217,7 @@ int tick(E* e) {
         }
         if (n_take > 0) {
           HIPOK(hipStreamWaitEvent(st, e->words_ev, 0));
+          if (e->take_ev_recorded) HIPOK(hipEventSynchronize(e->take_ev));   // the table built ahead still owns d_take / h_take
           hipLaunchKernelGGL(k_rng_take, dim3(nblk((long long)n_take)), dim3(BLK), 0, st, d.words, (unsigned long long)base,
                              (int)n_take, span, rshift, e->d_take);
           HIPOK(hipMemcpyAsync(e->h_take, e->d_take, n_take, hipMemcpyDeviceToHost, st));
@@ -358,6 +359,7 @@ int tick(E* e) {
                            (int)nt, span, rshift, e->d_take);
         HIPOK(hipMemcpyAsync(e->h_take, e->d_take, nt, hipMemcpyDeviceToHost, e->copy_stream));
         HIPOK(hipEventRecord(e->take_ev, e->copy_stream));
+        e->take_ev_recorded = true;
         e->take_base = nb; e->take_n = nt;
       }
     }
@@ -640,6 +642,15 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return TS_E_DEVICE;
   if (hipSetDevice(g_device) != hipSuccess) return TS_E_DEVICE;
+  {
+    // ranges the kernels rely on (int8 speed fields, the MAXB-cell bypass buffers, clz of the speed span)
+    const TsParams& q = *params;
+    if (q.vehicle_min_speed < 0 || q.vehicle_max_speed < q.vehicle_min_speed || q.vehicle_max_speed > 127) return TS_E_INVALID;
+    if (q.max_contraflow_overtake_steps < 0 || q.max_contraflow_stuck_detour_steps < 0 || q.vehicle_awareness_range < 0 ||
+        q.rain_speed_reduction < 0 || q.pathfinding_cooldown < 0)
+      return TS_E_INVALID;
+    if (q.max_contraflow_overtake_steps > MAXB || q.max_contraflow_stuck_detour_steps > MAXB) return TS_E_UNSUPPORTED;
+  }
   E* e = new E();
   memset(&e->d, 0, sizeof(e->d));
   memset(&e->C, 0, sizeof(e->C));
@@ -888,6 +899,8 @@ int ts_schedule_add(ts_handle e, int32_t kind, int32_t count) {
 
 int ts_set_traffic_generator(ts_handle e, const TsTrafficTables* t) {
   if (!e || !t || t->n_blocks < 0 || t->n_zones < 0 || t->n_zones > 8) return TS_E_INVALID;
+  if (t->blk_inner_cells && (t->food_consumption_ticks <= 0 || t->waste_production_ticks <= 0))
+    return fail(e, TS_E_INVALID, "food_consumption_ticks / waste_production_ticks must be positive");
   if (!e->rng_global.seeded()) return fail(e, TS_E_STATE, "seed the global stream before constructing the traffic generator");
   auto& G = e->gen;
   G.T = *t;
@@ -1007,9 +1020,10 @@ static int add_vehicles_core(ts_handle e, int n, std::vector<int32_t>& start, st
   int32_t *ds = nullptr, *dg = nullptr, *dp = nullptr, *dl = nullptr;
   uint32_t* dof = nullptr;
   uint8_t* dser = nullptr;
-  HIPOK(hipMalloc((void**)&ds, (size_t)n * 4)); HIPOK(hipMalloc((void**)&dg, (size_t)n * 4));
-  HIPOK(hipMalloc((void**)&dp, (size_t)n * 4)); HIPOK(hipMalloc((void**)&dl, (size_t)n * 4));
-  HIPOK(hipMalloc((void**)&dof, (size_t)n * 4)); HIPOK(hipMalloc((void**)&dser, (size_t)n));
+  struct Temps { void* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; ~Temps() { for (void* q : p) if (q) (void)hipFree(q); } } temps;
+  HIPOK(hipMalloc((void**)&ds, (size_t)n * 4)); temps.p[0] = ds; HIPOK(hipMalloc((void**)&dg, (size_t)n * 4)); temps.p[1] = dg;
+  HIPOK(hipMalloc((void**)&dp, (size_t)n * 4)); temps.p[2] = dp; HIPOK(hipMalloc((void**)&dl, (size_t)n * 4)); temps.p[3] = dl;
+  HIPOK(hipMalloc((void**)&dof, (size_t)n * 4)); temps.p[4] = dof; HIPOK(hipMalloc((void**)&dser, (size_t)n)); temps.p[5] = dser;
   HIPOK(hipMemcpyAsync(ds, start.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   HIPOK(hipMemcpyAsync(dg, goal.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   HIPOK(hipMemcpyAsync(dp, pop.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1025,7 +1039,6 @@ static int add_vehicles_core(ts_handle e, int n, std::vector<int32_t>& start, st
   HIPOK(hipStreamSynchronize(st));
   if (e->hint[0] > 0) hipLaunchKernelGGL(k_spawn_serial, dim3(1), dim3(64), 0, st, e->d, e->d_overflow, e->hint[0]);
   HIPOK(hipStreamSynchronize(st));
-  (void)hipFree(ds); (void)hipFree(dg); (void)hipFree(dp); (void)hipFree(dl); (void)hipFree(dof); (void)hipFree(dser);
   // live_* counters (city_model.py:1910-1918)
   long long add_int = 0, add_thr = 0;
   for (int i = 0; i < n; i++) { add_int += pop[i] == TS_POP_INTERNAL; add_thr += pop[i] == TS_POP_THROUGH; }
