@@ -1,251 +1,99 @@
-// astar.h - GPU A* (one search per wave) and the replanning policy of VehicleAgent.
+// astar.h - GPU A* (one search per wavefront, heap in LDS) and the replanning policy of VehicleAgent.
 //
-// astar_dev (one lane) and astar_wave (the same search spread over the 64 lanes of a wave; the one the replanning
-// kernels use) restate astar_numba.py:87-239 verbatim, quirks included:
+// astar_wave restates astar_numba.py:87-239 verbatim, quirks included:
 //   * binary heap keyed on f only, strict '<' in both sift routines (52-85);
 //   * dir_arr lives in heap-SLOT order and is NOT swapped by the sifts, so prev_dir = dir_arr[0] is a
 //     stale slot value (139, 147, 235);
 //   * `ng` is a double (R1 penalty 0.5) that truncates when stored into the int32 arrays (226-232);
 //   * soft-obstacle penalty int(1000 * (1 + 4 * density)) in double arithmetic on the float32 density.
-// Instead of the reference's O(W*H) per-call initialisation (119-122) every searcher owns an
-// epoch-stamped open-addressing table in HBM (dist / came_from by cell) and a private heap; a search
-// that outgrows its tier reports overflow and is re-run, unchanged, on a larger tier.
+// What is laid out for the machine instead of restated:
+//   * one wavefront = one search; the heap's first LDS_HEAP slots (f, cell: 8 bytes) and their dir bytes live in
+//     LDS, deeper levels spill to the searcher's HBM scratch.  g and steps are not carried in the heap: g = f - h(cell)
+//     exactly (h is an integer, ng >= 0), and the steps of a non-stale entry are those of the relaxation that wrote the
+//     table entry (every relaxation strictly lowers dist, so the entry with g == dist is the last one pushed);
+//   * dist / came_from / steps are one 8-byte record per cell in a table indexed DIRECTLY by the cell's position in an
+//     8 x 8-tiled order (no hashing, no probing, never outgrown), stamped with the searcher's epoch instead of the
+//     reference's O(W*H) initialisation per call (119-122).  A searcher's table is N x 8 bytes; the 288 GB of HBM
+//     hold several hundred of them even at 4096^2;
+//   * the maps a search reads are a per-tick snapshot in the same tiled order (Dev::amap: static byte + occupied +
+//     red, 2 bytes per cell = one 128-byte line per tile), so the neighbours of a cell usually share its line;
+//   * everything an expansion needs from HBM (5 map entries, 5 table records, 4 densities) is requested as soon as
+//     the popped cell is known and travels while the sift-down works in LDS: one memory round trip per expansion.
 //
 // decide_vehicle restates step_decide (vehicle_base.py:616-663) with _recompute_path_on_stuck 506-517,
 // _recompute_path_on_obstacle 454-504, _compute_path 143-167 and _compute_path_internal 199-420
 // (phases 0-4).  It is a pure function of the tick-start state until its final commit, so the same code
 // runs in k_decide_main (one vehicle per lane, no scratch: bails out as soon as a search is needed) and in
-// k_decide_replan (one vehicle per wave, every lane executing the same code on the same values).
+// k_replan (one vehicle per wave, every lane executing the same code on the same values).
 #pragma once
 #include "dev.h"
 
 namespace {
 
 constexpr int A_INF = 0x3F3F3F3F;
+#ifdef TS_KDEBUG
+#define KDBG(...) do { } while (0)
+#define KMARK(k, v) do { if (lane_id() == 0 && blockIdx.x < 8) d.hdbg[blockIdx.x * 8 + (k)] = (v); } while (0)
+#else
+#define KMARK(k, v) do { } while (0)
+#define KDBG(...) do { } while (0)
+#endif
 constexpr int MAXB = 64;  // longest contraflow bypass (VEHICLE_MAX_CONTRAFLOW_*_STEPS <= 64)
 enum { DV_DONE = 0, DV_DEFER = 1, DV_OVERFLOW = 2, DV_POOL_FULL = 3 };
 
-// 16-byte records so that one probe / one heap level is one dwordx4 access
-struct __attribute__((aligned(16))) HEnt { int32_t key, dist, came; uint32_t stamp; };   // dist / came_from by cell
-struct __attribute__((aligned(16))) QEnt { int32_t f, g, s, i; };                        // heap entry (f_arr, g_arr, s_arr, i_arr)
+constexpr int LDS_HEAP = 4096;            // heap slots (and dir bytes) a searcher keeps in LDS: 36 KB, four searchers per CU
+struct __attribute__((aligned(8))) HQ { int32_t f, i; };             // heap entry: f_arr, i_arr (g_arr / s_arr: see above)
+struct __attribute__((aligned(8))) TEnt { int32_t dist; uint32_t meta; };   // meta = stamp << 14 | steps << 2 | came-from direction
+constexpr uint32_t T_STAMP_SHIFT = 14, T_STEPS_MASK = 0xFFF, T_STAMP_MAX = (1u << 18) - 1;
+constexpr int A_STEPS_MAX = (int)T_STEPS_MASK - 1;   // largest binding step limit a search can carry (a limit >= N never binds)
 
-// One searcher's scratch (all in HBM, carved from a tier arena).
+__shared__ HQ g_lq[LDS_HEAP];
+__shared__ int8_t g_ld[LDS_HEAP];
+__shared__ int g_job;   // k_replan: the work-queue entry the wave is on
+
+// One searcher's scratch: LDS heap (above) + its slot of the HBM arena.
 struct AScratch {
-  HEnt* ht;
-  uint32_t hmask;
-  QEnt* hq;
-  int8_t* hd;   // dir_arr: indexed by heap SLOT and deliberately not moved by the sift routines
+  HQ* gq;        // heap slots [LDS_HEAP, heap_cap), indexed by slot - LDS_HEAP
+  int8_t* gd;    // dir_arr for the same slots: indexed by heap SLOT and deliberately not moved by the sift routines
   int heap_cap;
+  TEnt* tab;     // W8 * H8 * 64 records, tiled order
+  uint32_t epoch;
   int32_t *A, *P, *T, *PO, *PD;  // cap cells each: A* result, current new path, splice target, staged pre-paths
   int32_t *BYP, *OV, *DV;        // MAXB cells each: bypass result, staged overtake / detour paths
   int cap;        // capacity of the cell buffers
-  int node_cap;   // distinct cells the table may hold
-  uint32_t epoch;
-  int nodes;
-  int peak_nodes;   // largest table population any search of this vehicle reached (for the tier hint)
+  int use_reach;  // phase 1 asks reach_strict_wave before it searches (off: TS_NO_REACH, a debugging switch)
   long long calls, expansions, relaxations;
 };
 struct RLists { int32_t* l[6]; };       // replan work lists, see run_replans (engine.hip)
-struct StageCaps { int nodes[5]; };     // node capacity of each replanning stage
-// work list / counter a vehicle waiting for stage h is queued on
-__device__ __forceinline__ int stage_list(int h) { return h == 0 ? 0 : h == 1 ? 4 : h == 2 ? 1 : h == 3 ? 2 : 5; }
-__device__ __forceinline__ int stage_counter(int h) { return h == 0 ? 0 : h == 1 ? 5 : h == 2 ? 1 : h == 3 ? 2 : 6; }
-__device__ __forceinline__ void note_tier(const Dev& d, const AScratch& S, int vid, int stage, const StageCaps& caps) {
-  if (S.calls == 0) return;
-  int h = stage;
-  while (h > 0 && 2 * S.peak_nodes <= caps.nodes[h - 1]) h--;
-  d.tier_hint[vid] = (uint8_t)h;
-}
 
-struct ATier {
-  int cap, n_slots, heap_cap;
-  uint32_t hsize;  // power of two >= 2 * cap
-  HEnt* ht;
-  QEnt* hq;
-  int8_t* hd;
-  int32_t* cells;      // per slot: 5 * cap + 3 * MAXB
+struct ASlots {
+  int n_slots, heap_cap, cap, use_reach;
+  size_t tab_entries;    // per slot
+  TEnt* tab;
+  HQ* gq;
+  int8_t* gd;
+  int32_t* cells;        // per slot: 5 * cap + 3 * MAXB
   uint32_t* slot_epoch;
 };
 
-__device__ __forceinline__ void scratch_bind(const ATier& t, int slot, AScratch& S) {
-  S.ht = t.ht + (size_t)slot * t.hsize;
-  S.hmask = t.hsize - 1;
-  S.hq = t.hq + (size_t)slot * t.heap_cap;
-  S.hd = t.hd + (size_t)slot * t.heap_cap;
+__device__ __forceinline__ void scratch_bind(const ASlots& t, int slot, AScratch& S) {
+  S.tab = t.tab + (size_t)slot * t.tab_entries;
+  S.gq = t.gq + (size_t)slot * (size_t)(t.heap_cap - LDS_HEAP);
+  S.gd = t.gd + (size_t)slot * (size_t)(t.heap_cap - LDS_HEAP);
   S.heap_cap = t.heap_cap;
   int32_t* c = t.cells + (size_t)slot * ((size_t)5 * t.cap + 3 * MAXB);
   S.A = c; S.P = c + t.cap; S.T = c + 2 * (size_t)t.cap; S.PO = c + 3 * (size_t)t.cap; S.PD = c + 4 * (size_t)t.cap;
   S.BYP = c + 5 * (size_t)t.cap; S.OV = S.BYP + MAXB; S.DV = S.OV + MAXB;
   S.cap = t.cap;
-  S.node_cap = t.cap;
+  S.use_reach = t.use_reach;
   S.epoch = t.slot_epoch[slot];
-  S.peak_nodes = 0;
-  S.nodes = 0; S.calls = 0; S.expansions = 0; S.relaxations = 0;
+  S.calls = 0; S.expansions = 0; S.relaxations = 0;
+}
+// replanning class (work-queue order: largest first) from the expansions the vehicle's last replan took
+__device__ __forceinline__ int cost_class(long long expansions) {
+  return expansions < 2048 ? 0 : expansions < 32768 ? 1 : expansions < 262144 ? 2 : 3;
 }
 
-__device__ __forceinline__ uint32_t h_hash(int cell, uint32_t mask) { return ((uint32_t)cell * 2654435761u >> 7) & mask; }
-
-// returns the slot of `cell` (found) or the empty slot where it would go; `ent` = the record read there
-__device__ __forceinline__ uint32_t h_probe(const AScratch& S, int cell, bool& found, HEnt& ent) {
-  uint32_t h = h_hash(cell, S.hmask);
-  for (;;) {
-    ent = S.ht[h];
-    if (ent.stamp != S.epoch) { found = false; return h; }
-    if (ent.key == cell) { found = true; return h; }
-    h = (h + 1) & S.hmask;
-  }
-}
-
-// astar_core.  Writes the path (start excluded, goal included) to out[0..len); returns len >= 0, or -1 on
-// tier overflow (table, heap or output capacity).
-__device__ int astar_dev(const Dev& d, const TsParams& P, AScratch& S, int start_idx, int goal_idx, bool soft,
-                         bool ignore_flow, int maximum_steps, int32_t* out, int out_cap) {
-  const int W = d.W, H = d.H;
-  S.calls++;
-  S.epoch++;
-  if (S.epoch == 0) {  // stamp wrapped (once per 2^32 searches): clear the table
-    for (uint32_t q = 0; q <= S.hmask; q++) S.ht[q].stamp = 0;
-    S.epoch = 1;
-  }
-  S.nodes = 0;
-  const int gx = goal_idx % W, gy = goal_idx / W;
-  {
-    bool f; HEnt e;
-    uint32_t h = h_probe(S, start_idx, f, e);
-    S.ht[h] = HEnt{start_idx, 0, -1, S.epoch};
-    S.nodes = 1;
-  }
-  int heap_size = 1;
-  {
-    int sx = start_idx % W, sy = start_idx / W;
-    S.hq[0] = QEnt{abs(sx - gx) + abs(sy - gy), 0, 0, start_idx};
-    S.hd[0] = -1;
-  }
-  while (heap_size > 0) {
-    const QEnt top = S.hq[0];
-    const int g = top.g, steps = top.s, cur = top.i;
-    const int prev_dir = S.hd[0];
-    heap_size--;
-    if (heap_size > 0) {
-      // replace the root with the last entry and sift down (strict '<' on f, left child first)
-      QEnt x = S.hq[heap_size];
-      S.hd[0] = S.hd[heap_size];
-      int idx = 0;
-      for (;;) {
-        int left = 2 * idx + 1, right = left + 1;
-        if (left >= heap_size) break;
-        QEnt l = S.hq[left];
-        int smallest = idx;
-        int fs = x.f;
-        QEnt c = x;
-        if (l.f < fs) { smallest = left; fs = l.f; c = l; }
-        if (right < heap_size) {
-          QEnt r = S.hq[right];
-          if (r.f < fs) { smallest = right; c = r; }
-        }
-        if (smallest == idx) break;
-        S.hq[idx] = c;     // the child moves up; x keeps sinking
-        idx = smallest;
-      }
-      S.hq[idx] = x;
-    }
-    if (cur == goal_idx) {
-      int len = 0;
-      for (int idx = cur; idx != start_idx;) {
-        bool f; HEnt e;
-        h_probe(S, idx, f, e);
-        idx = e.came;
-        len++;
-      }
-      if (len > out_cap) return -1;
-      int k = len;
-      for (int idx = cur; idx != start_idx;) {
-        out[--k] = idx;
-        bool f; HEnt e;
-        h_probe(S, idx, f, e);
-        idx = e.came;
-      }
-      return len;
-    }
-    {
-      bool f; HEnt e;
-      h_probe(S, cur, f, e);
-      if (g > (f ? e.dist : A_INF)) continue;
-    }
-    S.expansions++;
-    const int cx = cur % W, cy = cur / W;
-    const uint8_t bits = (uint8_t)st_allowed(d.cell[cur].stat);
-    for (int dd = 0; dd < 4; dd++) {
-      const int nx = cx + (dd == 1) - (dd == 3), ny = cy + (dd == 0) - (dd == 2);
-      if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
-      const int ns = steps + 1;
-      if (ns > maximum_steps) continue;
-      const int nidx = ny * W + nx;
-      double ng = g + 1;
-      if (P.turn_penalty_enabled && prev_dir != -1 && dd != prev_dir) ng += P.turn_penalty;
-      const Cell nc = d.cell[nidx];   // one 32-byte load: occupancy, stop and the static byte of the neighbour
-      if ((bits & (1 << dd)) == 0) {
-        if (ignore_flow && st_is_road(nc.stat) == 1) ng += P.contraflow_penalty;
-        else continue;
-      }
-      if (nc.occ == 1) {
-        if (soft && P.dynamic_penalties_enabled) {
-          double p = P.obstacle_penalty_vehicle;
-          double local_density = (double)d.density[nidx];
-          ng += (double)(long long)(p * (1.0 + P.dynamic_penalty_scale * local_density));
-        } else if (soft) ng += P.obstacle_penalty_vehicle;
-        else continue;
-      }
-      if (nc.stop == 1) {
-        if (soft) ng += P.obstacle_penalty_stop;
-        else continue;
-      }
-      if (P.road_type_penalties_enabled && st_is_road(nc.stat) == 1) {
-        int rt = st_road_type(nc.stat);
-        if (rt == 1) ng += P.road_type_penalty_r1;
-        else if (rt == 2) ng += P.road_type_penalty_r2;
-        else if (rt == 3) ng += P.road_type_penalty_r3;
-      }
-      bool found; HEnt e;
-      uint32_t h = h_probe(S, nidx, found, e);
-      if (ng < (double)(found ? e.dist : A_INF)) {
-        S.relaxations++;
-        if (!found) {
-          if (S.nodes >= S.node_cap) return -1;
-          S.nodes++;
-          if (S.nodes > S.peak_nodes) S.peak_nodes = S.nodes;
-        }
-        S.ht[h] = HEnt{nidx, (int)ng, cur, S.epoch};
-        if (heap_size >= S.heap_cap) return -1;
-        // heap push at slot heap_size + sift up; dir_arr[slot] is written once and stays with the SLOT
-        QEnt x{(int)(ng + (double)(abs(nx - gx) + abs(ny - gy))), (int)ng, ns, nidx};
-        int i = heap_size;
-        S.hd[i] = (int8_t)dd;
-        while (i > 0) {
-          int parent = (i - 1) / 2;
-          QEnt pe = S.hq[parent];
-          if (x.f < pe.f) { S.hq[i] = pe; i = parent; } else break;
-        }
-        S.hq[i] = x;
-        heap_size++;
-      }
-    }
-  }
-  return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same search spread over one wavefront.  All 64 lanes call it with identical arguments and get the same
-// return value; the scratch (table, heap, dir bytes, output) is the searcher's, as for astar_dev.  The algorithm is
-// the sequential one - same heap layout, same comparisons, same order of relaxations - only its memory traffic
-// is organised by lanes so that a step costs one round trip instead of one per access:
-//   * sift-down: the 62 entries of the next five levels below the hole are fetched at once (one per lane) and the
-//     walk down those levels reads them with cross-lane shuffles;
-//   * sift-up of a push: the (at most 31) ancestors of the new slot are fetched at once, a ballot finds how far
-//     the entry rises, the lanes holding ancestors write them one level down in parallel;
-//   * the four neighbours are prepared on lanes 0-3 (cell record, density, table probe), then committed in the
-//     reference's order N, E, S, W.
-// ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_wave_barrier(); }
 // values every lane holds alike: tell the compiler (scalar registers, scalar branches) / read one lane's copy
@@ -258,83 +106,118 @@ __device__ __forceinline__ double rl(double v, int lane) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// heap slot k / its dir byte: LDS below LDS_HEAP, the searcher's HBM spill above (gq / gd are the slot's spill arrays)
+__device__ __forceinline__ HQ hq_get(const HQ* gq, int k) { return k < LDS_HEAP ? g_lq[k] : gq[k - LDS_HEAP]; }
+__device__ __forceinline__ void hq_put(HQ* gq, int k, HQ v) { if (k < LDS_HEAP) g_lq[k] = v; else gq[k - LDS_HEAP] = v; }
+__device__ __forceinline__ int hd_get(const int8_t* gd, int k) { return k < LDS_HEAP ? (int)g_ld[k] : (int)gd[k - LDS_HEAP]; }
+__device__ __forceinline__ void hd_put(int8_t* gd, int k, int v) { if (k < LDS_HEAP) g_ld[k] = (int8_t)v; else gd[k - LDS_HEAP] = (int8_t)v; }
+
+// a fresh epoch for the searcher's table (cleared by the wave when the 18-bit stamp wraps)
+__device__ __forceinline__ uint32_t next_epoch(const Dev& d, AScratch& S) {
+  if (S.epoch >= T_STAMP_MAX) {
+    const size_t n = (size_t)d.W8 * d.H8 * 64;
+    for (size_t q = lane_id(); q < n; q += 64) S.tab[q] = TEnt{0, 0u};
+    S.epoch = 0;
+    __syncthreads();
+  }
+  return ++S.epoch;
+}
+
+// ---------------------------------------------------------------------------------------------
+// astar_core, one search spread over one wavefront.  All 64 lanes call it with identical arguments and get the
+// same return value.  The algorithm is the sequential one - same heap layout, same comparisons, same order of
+// relaxations - only its memory traffic is organised by lanes:
+//   * sift-down: the 62 entries of the next five levels below the hole are fetched at once (one per lane) and the
+//     walk down those levels reads them with cross-lane reads;
+//   * sift-up of a push: the ancestors of the new slot are fetched at once, a ballot finds how far the entry rises,
+//     the lanes holding ancestors write them one level down in parallel;
+//   * the four neighbours are prepared on lanes 0-3 (map entry, density, table record; lane 4 holds the popped cell's
+//     own), then committed in the reference's order N, E, S, W.
+// Writes the path (start excluded, goal included) to out[0..len); returns len >= 0, or -1 when the heap or the
+// output buffer is too small.
+// ---------------------------------------------------------------------------------------------
 __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int start_idx, int goal_idx, bool soft,
                           bool ignore_flow, int maximum_steps, int32_t* out, int out_cap) {
   const int W = d.W, H = d.H;
   const int lane = lane_id();
+  // the arguments arrive in vector registers: tell the compiler they are wave-uniform (scalar loop control)
+  start_idx = uni(start_idx); goal_idx = uni(goal_idx); maximum_steps = uni(maximum_steps); out_cap = uni(out_cap);
+  soft = uni((int)soft) != 0; ignore_flow = uni((int)ignore_flow) != 0;
   S.calls++;
-  S.epoch++;
-  if (S.epoch == 0) {
-    for (uint32_t q = lane; q <= S.hmask; q += 64) S.ht[q].stamp = 0;
-    S.epoch = 1;
-    wave_mem_sync();
-  }
-  S.nodes = 0;
-  int gx, gy;
+  const uint32_t epoch = (uint32_t)uni((int)next_epoch(d, S));
+  KMARK(6, start_idx); KMARK(7, goal_idx); KMARK(0, 200 + (int)soft * 2 + (int)ignore_flow);
+  // the searcher's arrays and counters in registers for the loop (S itself may live in scratch memory)
+  HQ* const gq = S.gq;
+  int8_t* const gd = S.gd;
+  TEnt* const tab = S.tab;
+  const int heap_cap = uni(S.heap_cap);
+  long long n_exp = 0, n_relax = 0;
+  const uint32_t stamp = epoch << T_STAMP_SHIFT;
+  // the chain of relaxations behind a heap entry never revisits a cell (dist strictly falls), so it is shorter than
+  // N: a limit of N or more never binds and the steps need not be carried
+  const bool limited = maximum_steps < d.N;
+  int gx, gy, sx, sy;
   cell_xy(d, goal_idx, gx, gy);
-  {
-    bool f; HEnt e;
-    uint32_t h = h_probe(S, start_idx, f, e);
-    if (lane == 0) S.ht[h] = HEnt{start_idx, 0, -1, S.epoch};
-    S.nodes = 1;
-    if (S.nodes > S.peak_nodes) S.peak_nodes = S.nodes;
+  cell_xy(d, start_idx, sx, sy);
+  if (lane == 0) {
+    tab[tix(d, sx, sy)] = TEnt{0, stamp};
+    g_lq[0] = HQ{abs(sx - gx) + abs(sy - gy), start_idx};
+    g_ld[0] = -1;
   }
   int heap_size = 1;
-  {
-    int sx, sy;
-    cell_xy(d, start_idx, sx, sy);
-    if (lane == 0) { S.hq[0] = QEnt{abs(sx - gx) + abs(sy - gy), 0, 0, start_idx}; S.hd[0] = -1; }
-  }
   wave_mem_sync();
   // relative position of this lane inside a 63-entry window hanging below a hole: level and offset in the level
-  const int rel = lane;                                  // 0 = the hole itself (unused), 1..62 = five levels below it
-  const int rlvl = 31 - __builtin_clz((unsigned)(rel + 1));   // 0 for rel 0, 1 for 1-2, ... 5 for 31-62
-  const int roff = (rel + 1) - (1 << rlvl);
+  const int rlvl = 31 - __builtin_clz((unsigned)(lane + 1));   // 0 for lane 0, 1 for 1-2, ... 5 for 31-62
+  const int roff = (lane + 1) - (1 << rlvl);
+  const bool dens_on = soft && P.dynamic_penalties_enabled;
+  long long guard = 0;
   while (heap_size > 0) {
-    const QEnt top = S.hq[0];
-    const int g = uni(top.g), steps = uni(top.s), cur = uni(top.i);
-    const int prev_dir = uni((int)S.hd[0]);
+    if ((guard & 1023) == 0) { KMARK(4, (int)guard); KMARK(5, heap_size); }
+    if (++guard > (1ll << 21)) { if (lane == 0 && atomicCAS(&d.cnt->dbg[0], 0, 1) == 0) { d.cnt->dbg[1] = start_idx; d.cnt->dbg[2] = goal_idx; d.cnt->dbg[3] = heap_size; d.cnt->dbg[4] = (int)n_exp; d.cnt->dbg[5] = maximum_steps; d.cnt->dbg[6] = soft * 2 + ignore_flow; d.cnt->dbg[7] = (int)epoch; } return -1; }
+    const HQ top = g_lq[0];
+    const int f_top = uni(top.f), cur = uni(top.i);
+    const int prev_dir = uni((int)g_ld[0]);
     heap_size--;
-    // Everything the expansion of `cur` will read besides the heap is requested now, so that it travels while the
-    // sift-down below works on the heap (which it does not touch): the cell record of `cur`, and on lanes 0-3 the
-    // record, density and first table probe of neighbour `lane`; on every lane the first probe of `cur` itself.
+    // Everything the expansion of `cur` will read from HBM is requested now, so that it travels while the sift-down
+    // below works on the heap: lanes 0-3 the map entry, table record and density of neighbour `lane`, every other
+    // lane those of `cur` itself (lane 4 is the one read back).
     int cx, cy;
     cell_xy(d, cur, cx, cy);
     const int dd_l = lane & 3;
-    const int nx_l = cx + (dd_l == 1) - (dd_l == 3), ny_l = cy + (dd_l == 0) - (dd_l == 2);
-    const bool inb_l = lane < 4 && nx_l >= 0 && nx_l < W && ny_l >= 0 && ny_l < H;
+    const int nx_l = lane < 4 ? cx + (dd_l == 1) - (dd_l == 3) : cx, ny_l = lane < 4 ? cy + (dd_l == 0) - (dd_l == 2) : cy;
+    const bool inb_l = nx_l >= 0 && nx_l < W && ny_l >= 0 && ny_l < H;
     const int nidx_l = inb_l ? ny_l * W + nx_l : cur;
-    const uint32_t cur_dw = *reinterpret_cast<const uint32_t*>(&d.cell[cur].occ);
-    const uint32_t dyn_l = *reinterpret_cast<const uint32_t*>(&d.cell[nidx_l].occ);
-    const float dens_l = soft && P.dynamic_penalties_enabled ? d.density[nidx_l] : 0.f;
-    const uint32_t slot_l = h_hash(nidx_l, S.hmask), slot_c = h_hash(cur, S.hmask);
-    const HEnt first_l = S.ht[slot_l], first_c = S.ht[slot_c];
+    const uint32_t t_l = inb_l ? tix(d, nx_l, ny_l) : tix(d, cx, cy);
+    const uint32_t a_l = d.amap[t_l];
+    const TEnt e_l = tab[t_l];
+    const float dens_l = dens_on && lane < 4 ? d.density[nidx_l] : 0.f;
     if (heap_size > 0) {
-      QEnt x = S.hq[heap_size];
-      x.f = uni(x.f); x.g = uni(x.g); x.s = uni(x.s); x.i = uni(x.i);
-      const int8_t xd = (int8_t)uni((int)S.hd[heap_size]);
-      wave_mem_sync();                     // every lane has read hd[0] / hq[0] before they are overwritten
-      if (lane == 0) S.hd[0] = xd;
-      long long idx = 0;                   // the hole; x keeps sinking
+      HQ x = hq_get(gq, heap_size);
+      x.f = uni(x.f); x.i = uni(x.i);
+      const int xd = uni(hd_get(gd, heap_size));
+      wave_mem_sync();                     // every lane has read slot 0 before it is overwritten
+      if (lane == 0) g_ld[0] = (int8_t)xd;
+      int idx = 0;                         // the hole; x keeps sinking
       bool placed = false;
+      int wguard = 0;
       while (!placed) {
+        if (++wguard > 64) { if (lane == 0 && atomicCAS(&d.cnt->dbg[0], 0, 2) == 0) { d.cnt->dbg[1] = heap_size; d.cnt->dbg[2] = idx; } return -1; }
         // fetch the window below the hole
-        const long long abs_l = ((idx + 1) << rlvl) + roff - 1;
+        const int abs_l = ((idx + 1) << rlvl) + roff - 1;
         const bool in_heap = lane >= 1 && lane <= 62 && abs_l < heap_size;
-        QEnt mine = in_heap ? S.hq[abs_l] : QEnt{0x7FFFFFFF, 0, 0, 0};
-        int cur_rel = 0;
-        long long cur_abs = idx;
+        HQ mine = in_heap ? hq_get(gq, abs_l) : HQ{0x7FFFFFFF, 0};
+        int cur_rel = 0, cur_abs = idx;
 #pragma unroll
         for (int lv = 0; lv < 5; lv++) {
           const int l_rel = 2 * cur_rel + 1, r_rel = l_rel + 1;
-          const long long l_abs = 2 * cur_abs + 1, r_abs = l_abs + 1;
-          if (l_abs >= heap_size) { if (lane == 0) S.hq[cur_abs] = x; placed = true; break; }
+          const int l_abs = 2 * cur_abs + 1, r_abs = l_abs + 1;
+          if (l_abs >= heap_size) { if (lane == 0) hq_put(gq, cur_abs, x); placed = true; break; }
           const int lf = rl(mine.f, l_rel), rf = rl(mine.f, r_rel);
           int smallest = cur_rel, fs = x.f;
           if (lf < fs) { smallest = l_rel; fs = lf; }
           if (r_abs < heap_size && rf < fs) smallest = r_rel;
-          if (smallest == cur_rel) { if (lane == 0) S.hq[cur_abs] = x; placed = true; break; }
-          if (lane == smallest) S.hq[cur_abs] = mine;     // the child moves up
+          if (smallest == cur_rel) { if (lane == 0) hq_put(gq, cur_abs, x); placed = true; break; }
+          if (lane == smallest) hq_put(gq, cur_abs, mine);     // the child moves up
           cur_abs = smallest == l_rel ? l_abs : r_abs;
           cur_rel = smallest;
         }
@@ -343,47 +226,46 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
     }
     wave_mem_sync();
     if (cur == goal_idx) {
-      int len = 0;
-      for (int idx = cur; idx != start_idx;) {
-        bool f; HEnt e;
-        h_probe(S, idx, f, e);
-        idx = e.came;
+      // walk came_from back to the start, filling the output from its far end, then slide it to the front
+      int len = 0, x = cx, y = cy;
+      for (int c = cur; c != start_idx;) {
+        if (x < 0 || x >= W || y < 0 || y >= H) { if (lane == 0 && atomicCAS(&d.cnt->dbg[0], 0, 3) == 0) { d.cnt->dbg[1] = start_idx; d.cnt->dbg[2] = goal_idx; d.cnt->dbg[3] = len; d.cnt->dbg[4] = x; d.cnt->dbg[5] = y; } return -1; }
+        if (len >= out_cap) { S.expansions += n_exp; S.relaxations += n_relax; return -1; }
+        if (lane == 0) out[out_cap - 1 - len] = c;
         len++;
+        const int dd = (int)(tab[tix(d, x, y)].meta & 3u);
+        x -= (dd == 1) - (dd == 3); y -= (dd == 0) - (dd == 2);
+        c = y * W + x;
       }
-      if (len > out_cap) return -1;
-      int k = len;
-      for (int idx = cur; idx != start_idx;) {
-        --k;
-        if (lane == 0) out[k] = idx;
-        bool f; HEnt e;
-        h_probe(S, idx, f, e);
-        idx = e.came;
-      }
-      wave_mem_sync();
+      __syncthreads();
+      const int shift = out_cap - len;
+      if (shift > 0)
+        for (int k0 = 0; k0 < len; k0 += 64) {
+          const int k = k0 + lane;
+          const int v = k < len ? out[shift + k] : 0;
+          if (k < len) out[k] = v;
+        }
+      __syncthreads();
+      S.expansions += n_exp; S.relaxations += n_relax;
+      KDBG("[k] b%d astar found len=%d exp=%lld\n", (int)blockIdx.x, len, n_exp);
       return len;
     }
+    const int g = f_top - (abs(cx - gx) + abs(cy - gy));
+    const uint32_t m_c = (uint32_t)rl((int)e_l.meta, 4);
     {
-      bool f; HEnt e = first_c;
-      uint32_t h = slot_c;
-      for (;;) {   // continue the probe of `cur` from the record fetched above
-        if (e.stamp != S.epoch) { f = false; break; }
-        if (e.key == cur) { f = true; break; }
-        h = (h + 1) & S.hmask;
-        e = S.ht[h];
-      }
-      if (uni((int)(g > (f ? e.dist : A_INF)))) continue;
+      const int dist_c = (m_c >> T_STAMP_SHIFT) == epoch ? rl(e_l.dist, 4) : A_INF;
+      if (g > dist_c) continue;
     }
-    S.expansions++;
-    const uint8_t bits = (uint8_t)st_allowed((uint8_t)(cur_dw >> 24));
+    n_exp++;
+    const int steps = limited ? (int)((m_c >> 2) & T_STEPS_MASK) : 0;
+    const uint8_t bits = (uint8_t)st_allowed((uint8_t)((uint32_t)rl((int)a_l, 4) & 0xFF));
     // ---- prepare: lane dd < 4 evaluates neighbour dd from what was fetched before the sift-down ---------------
-    bool ok_l = inb_l && steps + 1 <= maximum_steps;
+    bool ok_l = lane < 4 && inb_l && steps + 1 <= maximum_steps;
     double ng_l = g + 1;
-    bool found_l = false;
-    HEnt e_l = first_l;
-    uint32_t h_l = slot_l;
+    const bool found_l = (e_l.meta >> T_STAMP_SHIFT) == epoch;
     if (ok_l) {
-      const int n_occ = (int8_t)(dyn_l & 0xFF), n_stop = (int8_t)((dyn_l >> 8) & 0xFF);
-      const uint8_t n_stat = (uint8_t)(dyn_l >> 24);
+      const int n_occ = (int)((a_l >> 8) & 1u), n_stop = (int)((a_l >> 9) & 1u);
+      const uint8_t n_stat = (uint8_t)(a_l & 0xFF);
       if (P.turn_penalty_enabled && prev_dir != -1 && dd_l != prev_dir) ng_l += P.turn_penalty;
       if ((bits & (1 << dd_l)) == 0) {
         if (ignore_flow && st_is_road(n_stat) == 1) ng_l += P.contraflow_penalty;
@@ -407,58 +289,90 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
         else if (rt == 2) ng_l += P.road_type_penalty_r2;
         else if (rt == 3) ng_l += P.road_type_penalty_r3;
       }
-      if (ok_l) {   // continue the probe from the record fetched above
-        for (;;) {
-          if (e_l.stamp != S.epoch) { found_l = false; break; }
-          if (e_l.key == nidx_l) { found_l = true; break; }
-          h_l = (h_l + 1) & S.hmask;
-          e_l = S.ht[h_l];
-        }
-      }
+      if (ok_l && !(ng_l < (double)(found_l ? e_l.dist : A_INF))) ok_l = false;
     }
-    // ---- commit in the reference's order --------------------------------------------------------------------
-    bool table_grew = false;
-#pragma unroll
-    for (int dd = 0; dd < 4; dd++) {
-      if (!rl((int)ok_l, dd)) continue;
-      const int nidx = rl(nidx_l, dd);
+    // ---- commit in the reference's order (the four neighbours are distinct cells: no commit changes another's test)
+    unsigned relax = (unsigned)(__ballot(ok_l) & 15ull);
+    while (relax) {
+      const int dd = __builtin_ctz(relax);
+      relax &= relax - 1;
+      n_relax++;
+      if (heap_size >= heap_cap) { S.expansions += n_exp; S.relaxations += n_relax; return -1; }
       const double ng = rl(ng_l, dd);
-      bool found = rl((int)found_l, dd) != 0;
-      uint32_t h = (uint32_t)rl((int)h_l, dd);
-      int dist_n = rl(e_l.dist, dd);
-      if (table_grew) {   // a key went in since the probe: it may sit where this one would have gone
-        HEnt e;
-        h = (uint32_t)uni((int)h_probe(S, nidx, found, e));
-        found = uni((int)found) != 0;
-        dist_n = uni(e.dist);
-      }
-      if (!(ng < (double)(found ? dist_n : A_INF))) continue;
-      S.relaxations++;
-      if (!found) {
-        if (S.nodes >= S.node_cap) return -1;
-        S.nodes++;
-        if (S.nodes > S.peak_nodes) S.peak_nodes = S.nodes;
-        table_grew = true;
-      }
-      if (heap_size >= S.heap_cap) return -1;
-      const int nx = rl(nx_l, dd), ny = rl(ny_l, dd);
-      const QEnt x{(int)(ng + (double)(abs(nx - gx) + abs(ny - gy))), (int)ng, steps + 1, nidx};
-      const long long i = heap_size;
+      const int nidx = rl(nidx_l, dd), nx = rl(nx_l, dd), ny = rl(ny_l, dd);
+      const uint32_t t_n = (uint32_t)rl((int)t_l, dd);
+      const HQ x{(int)(ng + (double)(abs(nx - gx) + abs(ny - gy))), nidx};
+      const int i = heap_size;
       // ancestors of slot i: a_k = ((i + 1) >> k) - 1, k = 1 .. depth; lane k - 1 fetches a_k
-      const int depth = 63 - __builtin_clzll((unsigned long long)(i + 1));
-      const long long a_mine = ((i + 1) >> (lane + 1)) - 1;
-      const bool has = lane < depth;
-      const QEnt anc = has ? S.hq[a_mine] : QEnt{(int)0x80000000, 0, 0, 0};
+      const int depth = 31 - __builtin_clz((unsigned)(i + 1));
+      const bool has = lane < depth;                                  // depth <= 31: lanes beyond it fetch nothing
+      const int a_mine = has ? ((i + 1) >> (lane + 1)) - 1 : 0;      // (an unguarded shift by lane + 1 >= 32 is undefined)
+      const HQ anc = has ? hq_get(gq, a_mine) : HQ{(int)0x80000000, 0};
       const unsigned long long rises = __ballot(has && x.f < anc.f);
       const int r = rises == ~0ull ? 64 : __builtin_ctzll(~rises);      // leading ancestors the entry passes
-      if (lane == 0) { S.ht[h] = HEnt{nidx, (int)ng, cur, S.epoch}; S.hd[i] = (int8_t)dd; }
-      if (lane < r) S.hq[((i + 1) >> lane) - 1] = anc;                 // ancestor k moves to where k - 1 was
-      if (lane == 0) S.hq[((i + 1) >> r) - 1] = x;
+      if (lane == 0) {
+        tab[t_n] = TEnt{(int)ng, stamp | (limited ? (uint32_t)(steps + 1) << 2 : 0u) | (uint32_t)dd};
+        hd_put(gd, i, dd);
+      }
+      if (lane < r) hq_put(gq, ((i + 1) >> lane) - 1, anc);             // ancestor k moves to where k - 1 was
+      if (lane == 0) hq_put(gq, ((i + 1) >> r) - 1, x);
       heap_size++;
       wave_mem_sync();
     }
   }
+  S.expansions += n_exp; S.relaxations += n_relax;
+  KDBG("[k] b%d astar empty exp=%lld\n", (int)blockIdx.x, n_exp);
   return 0;
+}
+
+// Strict reachability of `goal` from `start`: a frontier BFS by the wave over the same edges the strict A* relaxes
+// (flow bit set, neighbour in bounds, neither occupied nor red), 64 cells per step.  Unreachable targets are by far
+// the most expensive searches (the sequential search floods the whole component before returning []); knowing the
+// answer lets phase 1 skip them.  Visited marks are stamps of a fresh epoch in the searcher's own table, the queue is
+// a ring in its heap spill area.  Returns 1 reachable, 2 not, 0 unknown (ring overflow).
+__device__ int reach_strict_wave(const Dev& d, AScratch& S, int start, int goal) {
+  const int W = d.W, H = d.H, lane = lane_id();
+  start = uni(start); goal = uni(goal);
+  const uint32_t stamp = (uint32_t)uni((int)next_epoch(d, S)) << T_STAMP_SHIFT;
+  int32_t* ring = reinterpret_cast<int32_t*>(S.gq);
+  TEnt* const tab = S.tab;
+  const unsigned qcap = (unsigned)uni(S.heap_cap - LDS_HEAP) * 2u;
+  if (qcap < 256u) return 0;
+  if (lane == 0) {
+    int sx, sy;
+    cell_xy(d, start, sx, sy);
+    ring[0] = start;
+    tab[tix(d, sx, sy)].meta = stamp;
+  }
+  __syncthreads();
+  unsigned head = 0, tail = 1;
+  bool found = false;
+  while (head < tail && !found) {
+    const unsigned idx = head + (unsigned)lane;
+    const int c = idx < tail ? ring[idx % qcap] : -1;
+    head = min(tail, head + 64u);
+    int cx = 0, cy = 0;
+    if (c >= 0) cell_xy(d, c, cx, cy);
+    const uint32_t bits = c >= 0 ? (uint32_t)d.amap[tix(d, cx, cy)] & 15u : 0u;
+    for (int dd = 0; dd < 4; dd++) {
+      int n = -1;
+      if (bits & (1u << dd)) {
+        const int nx = cx + (dd == 1) - (dd == 3), ny = cy + (dd == 0) - (dd == 2);
+        if (nx >= 0 && nx < W && ny >= 0 && ny < H) {
+          const uint32_t tn = tix(d, nx, ny);
+          if (((uint32_t)d.amap[tn] & 0x300u) == 0u && atomicExch(&tab[tn].meta, stamp) != stamp) n = ny * W + nx;
+        }
+      }
+      const unsigned long long m = __ballot(n >= 0);
+      const unsigned cnt = (unsigned)__popcll(m);
+      if (tail + cnt - head > qcap) return 0;
+      if (n >= 0) ring[(tail + (unsigned)__popcll(m & ((1ULL << lane) - 1))) % qcap] = n;
+      if (__ballot(n == goal && n >= 0)) found = true;
+      tail += cnt;
+    }
+    __syncthreads();  // ring writes of this step are read by the next one
+  }
+  return found ? 1 : 2;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -476,7 +390,7 @@ struct VW {
   bool ax_staged[4];
   int ax_len[4];  // -1 = None
   int d_overtaking, d_detour;
-  bool reach_known;  // d.reach[vid] was computed for this tick's maps and this position
+  bool reach_known;  // a replan inside the decide phase: phase 1 asks reach_strict_wave first
 };
 
 __device__ __forceinline__ int32_t* ax_buf(const AScratch& S, int k) { return k == 0 ? S.OV : k == 1 ? S.PO : k == 2 ? S.DV : S.PD; }
@@ -569,8 +483,8 @@ __device__ __forceinline__ void swap_ptr(int32_t*& a, int32_t*& b) { int32_t* t 
 template <bool WAVE>
 __device__ __forceinline__ int astar_any(const Dev& d, const TsParams& P, AScratch& S, int start_idx, int goal_idx, bool soft,
                                          bool ignore_flow, int maximum_steps, int32_t* out, int out_cap) {
-  if (WAVE) return astar_wave(d, P, S, start_idx, goal_idx, soft, ignore_flow, maximum_steps, out, out_cap);
-  return astar_dev(d, P, S, start_idx, goal_idx, soft, ignore_flow, maximum_steps, out, out_cap);
+  if constexpr (WAVE) return astar_wave(d, P, S, start_idx, goal_idx, soft, ignore_flow, maximum_steps, out, out_cap);
+  else return -1;   // (one vehicle per lane never searches: decide_vehicle<false> defers before it gets here)
 }
 template <bool WAVE>
 __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScratch& S, VW& v, int& out_len) {
@@ -606,8 +520,10 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
   // ---- phase 1: strict; phase 2: soft obstacles (280-306) ----
   const int sx_goal = v.target;
   int la;
-  if (v.reach_known && d.reach[v.vid] == 2) {
-    // k_reach_strict proved the target unreachable under the strict rules: the search would flood its whole
+  bool unreachable = false;
+  if constexpr (WAVE) unreachable = v.reach_known && reach_strict_wave(d, S, v.pos, sx_goal) == 2;
+  if (unreachable) {
+    // the frontier BFS proved the target unreachable under the strict rules: the search would flood its whole
     // component and return [] (astar_numba.py:239).  Same result, without the flood.
     S.calls++;
     la = 0;
@@ -738,7 +654,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
   if (vid < 0) return DV_DONE;
   VW v;
   v.vid = vid; v.i = i; v.pos = d.pos[vid]; v.target = d.target[vid];
-  v.reach_known = S != nullptr;
+  v.reach_known = S != nullptr && S->use_reach;
   v.f = d.flags[vid] & ~VF_EARLY;
   const uint8_t ev = d.ev[vid];
   v.base = d.base_speed[vid]; v.cur = d.cur_speed[vid];
@@ -906,98 +822,98 @@ __global__ void k_decide_main(Dev d, TsParams P, int n_active, RLists lists) {
   if (i >= n_active) return;
   if (d.cnt->rng_event != 0xFFFFFFFFu) return;  // a malfunction / sideswipe fired: the host re-runs this after the fix-up
   if (decide_vehicle<false>(d, P, i, nullptr) == DV_DEFER) {
-    // start where its last search fitted, or where a search over this distance is likely to fit: the searches are
-    // Dijkstra-like (the heuristic is far below the penalties), so they touch on the order of md^2 / 2 cells
+    // work-queue class (largest first): what the vehicle's last replan cost, or what a search over this distance
+    // is likely to cost - the searches are Dijkstra-like (the heuristic is far below the penalties), so they touch
+    // on the order of md^2 / 2 cells
     const int vid = d.active[i];
     const int p0 = d.pos[vid], p1 = d.target[vid];
-    const int md = abs(p0 % d.W - p1 % d.W) + abs(p0 / d.W - p1 / d.W);
-    const int by_dist = md < 40 ? 0 : md < 60 ? 1 : md < 240 ? 2 : md < 680 ? 3 : 4;
-    const int h = min(max((int)d.tier_hint[vid], by_dist), 4);
-    lists.l[stage_list(h)][atomicAdd(&d.cnt->replan_n[stage_counter(h)], 1)] = i;
+    int x0, y0, x1, y1;
+    cell_xy(d, p0, x0, y0); cell_xy(d, p1, x1, y1);
+    const int md = abs(x0 - x1) + abs(y0 - y1);
+    const int by_dist = md < 60 ? 0 : md < 240 ? 1 : md < 680 ? 2 : 3;
+    const int h = min(max((int)d.tier_hint[vid], by_dist), 3);
+    lists.l[h][atomicAdd(&d.cnt->replan_n[h], 1)] = i;
   }
 }
 
-// replanning vehicles: one wave per vehicle, private scratch from tier `t`.  Entries that outgrow the tier go
-// to `next_list` (counter replan_n[next_counter]); entries that find the pool full go to `retry_list`.
-__global__ void __launch_bounds__(64) k_decide_replan(Dev d, TsParams P, ATier t, const int32_t* list, int begin, int n, int32_t* next_list,
-                                int next_counter, int32_t* retry_list, int stage, StageCaps caps) {
-  // one wave per vehicle (64 independent searches in one wave would run in lockstep and pay for each other's
-  // branches); all 64 lanes run the vehicle's step_decide together and share the work inside the searches
-  const int j = blockIdx.x;
-  if (j >= n) return;
-  AScratch S;
-  scratch_bind(t, j, S);
-  const int i = list[begin + j];
-  int r = decide_vehicle<true>(d, P, i, &S);
-  if (threadIdx.x != 0) return;
-  t.slot_epoch[j] = S.epoch;
-  if (r == DV_DONE) {  // work of attempts that are re-run on a larger tier / after pool growth is not counted twice
-    note_tier(d, S, d.active[i], stage, caps);
-    atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
-    atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
-    atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
-  }
-  if (r == DV_OVERFLOW) next_list[atomicAdd(&d.cnt->replan_n[next_counter], 1)] = i;
-  else if (r == DV_POOL_FULL) retry_list[atomicAdd(&d.cnt->replan_n[3], 1)] = i;
-}
-
-// The same, with the search structures (dist/came_from table and the heap) in LDS: one wave per vehicle, lane 0
-// runs the sequential algorithm.  A* is a chain of dependent accesses; what matters is the latency of each one,
-// and LDS answers several times faster than L2.  Searches that outgrow the LDS budget go to the HBM tiers.
-constexpr int LDS_NODES = 1024, LDS_HASH = 2048, LDS_HEAP = 2048;
-__global__ void __launch_bounds__(64) k_decide_replan_lds(Dev d, TsParams P, ATier cells_tier, const int32_t* list, int begin,
-                                                            int n, int32_t* next_list, int next_counter, int32_t* retry_list,
-                                                            StageCaps caps) {
-  __shared__ HEnt s_ht[LDS_HASH];
-  __shared__ QEnt s_hq[LDS_HEAP];
-  __shared__ int8_t s_hd[LDS_HEAP];
-  const int j = blockIdx.x;
-  if (j >= n) return;
-  for (int q = threadIdx.x; q < LDS_HASH; q += 64) s_ht[q].stamp = 0;
+// One turn of a searcher wave at the replanning work queue: take the next entry, run the vehicle's step_decide with
+// all 64 lanes, account for it.  Returns 0 once the queue is empty.  Kept out of line on purpose: inlined into
+// k_replan's loop, hipcc 7.2 threaded the lane-0-only parts (queue pop, accounting) of consecutive turns together and
+// let lane 0 run the loop on a path of its own, apart from the other 63 lanes - wrong for code whose lanes cooperate
+// through readlane / ballot.  A call boundary is a point where the wave is whole again.
+struct RQueue { int32_t* l[4]; int n[4]; int32_t *retry_list, *owned_list; int rank, world; };
+__device__ __attribute__((noinline)) int replan_turn(const Dev& d, const TsParams& P, AScratch* S, const RQueue& q) {
+  const int n3 = uni(q.n[3]), n2 = uni(q.n[2]), n1 = uni(q.n[1]), n0 = uni(q.n[0]);
+  if (threadIdx.x == 0) g_job = atomicAdd(&d.cnt->replan_n[5], 1);
   __syncthreads();
-  AScratch S;
-  scratch_bind(cells_tier, j, S);   // cell buffers (paths) from the arena of the first HBM tier
-  S.ht = s_ht; S.hmask = LDS_HASH - 1; S.hq = s_hq; S.hd = s_hd; S.heap_cap = LDS_HEAP;
-  S.node_cap = LDS_NODES;
-  S.peak_nodes = 0;
-  S.epoch = 0;
-  const int i = list[begin + j];
-  int r = decide_vehicle<true>(d, P, i, &S);
-  if (threadIdx.x != 0) return;
-  if (r == DV_DONE) {
-    note_tier(d, S, d.active[i], 0, caps);
-    atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
-    atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
-    atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
+  const int j = uni(g_job);
+  __syncthreads();
+  if (j >= n3 + n2 + n1 + n0) return 0;
+  int i;
+  if (j < n3) i = q.l[3][j];
+  else if (j < n3 + n2) i = q.l[2][j - n3];
+  else if (j < n3 + n2 + n1) i = q.l[1][j - n3 - n2];
+  else i = q.l[0][j - n3 - n2 - n1];
+  i = uni(i);
+  if (q.world > 1 && (i % q.world) != q.rank) return 1;
+  const long long c0 = S->calls, e0 = S->expansions, r0 = S->relaxations;
+  const int r = uni(decide_vehicle<true>(d, P, i, S));
+  if (threadIdx.x == 0) {
+    if (r == DV_DONE) {  // work of attempts that are re-run after pool growth is not counted twice
+      const int vid = d.active[i];
+      if (S->calls > c0) d.tier_hint[vid] = (uint8_t)cost_class(S->expansions - e0);
+      atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)(S->calls - c0));
+      atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)(S->expansions - e0));
+      atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)(S->relaxations - r0));
+      if (q.owned_list) q.owned_list[atomicAdd(&d.cnt->replan_n[6], 1)] = i;
+    } else if (r == DV_OVERFLOW) atomicExch(&d.cnt->error, TS_E_CAPACITY);
+    else if (r == DV_POOL_FULL) q.retry_list[atomicAdd(&d.cnt->replan_n[4], 1)] = i;
   }
-  if (r == DV_OVERFLOW) next_list[atomicAdd(&d.cnt->replan_n[next_counter], 1)] = i;
-  else if (r == DV_POOL_FULL) retry_list[atomicAdd(&d.cnt->replan_n[3], 1)] = i;
+  return 1;
 }
 
-// one search on the current maps (the `astar(...)` operator seam, ts_astar) - slot 0 of tier `t`
-__global__ void __launch_bounds__(64) k_astar_single(Dev d, TsParams P, ATier t, int start_idx, int goal_idx, int soft,
+// Replanning vehicles: a work queue served by one wave per searcher slot.  The queue is the four class lists, the
+// most expensive class first (a tick's replanning time is bounded below by its longest search: start those first and
+// let the short ones fill in behind).  Every wave takes the next entry until the queue is empty; all 64 lanes run
+// the vehicle's step_decide together and share the work inside the searches.  Entries that find the path pool
+// full go to `retry_list` (counter replan_n[4]); replan_n[5] is the queue cursor.
+// `world` > 1: the replicated-state multi-GPU mode - this rank plans only the vehicles whose decide-order index is
+// congruent to `rank`; the results travel through ts_replan_export / ts_replan_import.
+__global__ void __launch_bounds__(64) k_replan(Dev d, TsParams P, ASlots sl, RLists lists, int32_t* retry_list, int rank, int world,
+                                               int32_t* owned_list) {
+  AScratch S;
+  scratch_bind(sl, blockIdx.x, S);
+  RQueue q;
+  for (int c = 0; c < 4; c++) { q.l[c] = lists.l[c]; q.n[c] = d.cnt->replan_n[c]; }
+  q.retry_list = retry_list; q.owned_list = owned_list; q.rank = rank; q.world = world;
+  while (uni(replan_turn(d, P, &S, q))) {}
+  if (threadIdx.x == 0) sl.slot_epoch[blockIdx.x] = S.epoch;
+}
+
+// one search on the current maps (the `astar(...)` operator seam, ts_astar) - searcher slot 0
+__global__ void __launch_bounds__(64) k_astar_single(Dev d, TsParams P, ASlots sl, int start_idx, int goal_idx, int soft,
                                                       int ignore_flow, int maximum_steps, int32_t* out_len) {
   if (blockIdx.x) return;
   AScratch S;
-  scratch_bind(t, 0, S);
+  scratch_bind(sl, 0, S);
   int len = astar_wave(d, P, S, start_idx, goal_idx, soft != 0, ignore_flow != 0, maximum_steps, S.A, S.cap);
   if (threadIdx.x) return;
-  t.slot_epoch[0] = S.epoch;
+  sl.slot_epoch[0] = S.epoch;
   if (len >= 0) {
     atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
     atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
     atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
   }
-  *out_len = len;  // -1 = tier overflow; the path cells are in the slot's A buffer
+  *out_len = len;  // -1 = heap / output capacity exceeded; the path cells are in the slot's A buffer
 }
 
 // VehicleAgent.__init__ -> self.path = self._compute_path() on a cache miss (vehicle_base.py:80-81, 143-167):
 // the phase 0-4 planner for a freshly placed vehicle.  status: path length, or -1 overflow / -2 pool full.
-__global__ void __launch_bounds__(64) k_spawn_plan(Dev d, TsParams P, ATier t, int vid, int32_t* status) {
+__global__ void __launch_bounds__(64) k_spawn_plan(Dev d, TsParams P, ASlots sl, int vid, int32_t* status) {
   if (blockIdx.x) return;
   const bool one = threadIdx.x == 0;
   AScratch S;
-  scratch_bind(t, 0, S);
+  scratch_bind(sl, 0, S);
   VW v;
   v.vid = vid; v.i = LAST_IDX; v.pos = d.pos[vid]; v.target = d.target[vid];
   v.f = d.flags[vid]; v.base = 0; v.cur = 0; v.cooldown = P.pathfinding_cooldown;
@@ -1007,12 +923,12 @@ __global__ void __launch_bounds__(64) k_spawn_plan(Dev d, TsParams P, ATier t, i
   for (int k = 0; k < 4; k++) { v.ax_staged[k] = false; v.ax_len[k] = d.ax_len[k][vid]; }
   int len;
   bool ok = compute_path_internal_dev<true>(d, P, S, v, len);
-  t.slot_epoch[0] = S.epoch;
-  if (!ok) { *status = -1; return; }
+  if (one) sl.slot_epoch[0] = S.epoch;
+  if (!ok) { if (one) *status = -1; return; }
   int words = (len + 15) / 16;
   for (int k = 0; k < 4; k++) if (v.ax_staged[k]) words += (v.ax_len[k] + 15) / 16;
   uint32_t off = 0;
-  if (words > 0 && !pool_alloc<true>(d, words, off)) { *status = -2; return; }
+  if (words > 0 && !pool_alloc<true>(d, words, off)) { if (one) *status = -2; return; }
   if (one) {
     atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
     atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
@@ -1030,7 +946,7 @@ __global__ void __launch_bounds__(64) k_spawn_plan(Dev d, TsParams P, ATier t, i
   d.flags[vid] = v.f; d.over_dur[vid] = v.over_dur; d.det_dur[vid] = v.det_dur;
   if (one && v.d_overtaking) atomicAdd((unsigned long long*)&d.cnt->overtaking, (unsigned long long)v.d_overtaking);
   if (one && v.d_detour) atomicAdd((unsigned long long*)&d.cnt->in_stuck_detour, (unsigned long long)v.d_detour);
-  *status = len;
+  if (one) *status = len;
 }
 
 // path-pool garbage collection: every live vehicle copies the words it still needs into a fresh pool
@@ -1057,59 +973,6 @@ __global__ void k_pool_gc(Dev d, int n_active, uint32_t* new_pool, unsigned long
     for (int q = 0; q < words; q++) new_pool[dst + q] = d.pool[src + q];
     d.ax_off[k][vid] = dst;
   }
-}
-
-// Strict reachability of the target, one wave per replanning vehicle: a frontier BFS over the same edges the
-// strict A* relaxes (flow bit set, neighbour in bounds, neither occupied nor red).  Unreachable targets are by far
-// the most expensive searches (they flood the component before returning []); the flag lets phase 1 skip them.
-__global__ void k_reach_strict(Dev d, const int32_t* list, int n_list, uint32_t* visited_all, int32_t* queue_all,
-                               size_t words_per, size_t queue_per) {
-  const int w = blockIdx.x;
-  if (w >= n_list) return;
-  const int lane = threadIdx.x;
-  const int i = list[w];
-  const int vid = d.active[i];
-  if (vid < 0) return;
-  uint32_t* visited = visited_all + (size_t)w * words_per;
-  int32_t* queue = queue_all + (size_t)w * queue_per;
-  for (size_t q = lane; q < words_per; q += 64) visited[q] = 0;
-  const int start = d.pos[vid], goal = d.target[vid];
-  const int W = d.W, H = d.H;
-  __syncthreads();
-  if (lane == 0) { queue[0] = start; visited[start >> 5] = 1u << (start & 31); }
-  __syncthreads();
-  int head = 0, tail = 1;
-  bool found = false;
-  while (head < tail && !found) {
-    const int idx = head + lane;
-    const int c = idx < tail ? queue[idx] : -1;
-    head = min(tail, head + 64);
-    const uint8_t bits = c >= 0 ? (uint8_t)st_allowed(d.cell[c].stat) : 0;
-    const int cx = c >= 0 ? c % W : 0, cy = c >= 0 ? c / W : 0;
-    for (int dd = 0; dd < 4; dd++) {
-      int n = -1;
-      if (c >= 0 && (bits & (1 << dd))) {
-        const int nx = cx + (dd == 1) - (dd == 3), ny = cy + (dd == 0) - (dd == 2);
-        if (nx >= 0 && nx < W && ny >= 0 && ny < H) {
-          const int nidx = ny * W + nx;
-          const Cell nc = d.cell[nidx];
-          if (nc.occ != 1 && nc.stop != 1) {
-            const uint32_t bit = 1u << (nidx & 31);
-            if (!(atomicOr(&visited[nidx >> 5], bit) & bit)) n = nidx;
-          }
-        }
-      }
-      const unsigned long long m = __ballot(n >= 0);
-      if (n >= 0) {
-        const int off = __popcll(m & ((1ULL << lane) - 1));
-        if (tail + off < (int)queue_per) queue[tail + off] = n;
-      }
-      if (__ballot(n == goal && n >= 0)) found = true;
-      tail = min((int)queue_per, tail + (int)__popcll(m));
-    }
-    __syncthreads();  // queue writes of this step are read by the next one
-  }
-  if (lane == 0) d.reach[vid] = found ? 1 : 2;
 }
 
 }  // namespace

@@ -36,13 +36,14 @@ struct DevCnt {
   int deaths;      // vehicles removed this tick
   int arr_n;       // service records written this tick (Dev::arr)
   int error;       // sticky device-side error
-  int replan_n[8]; // work-list lengths, see run_replans (engine.hip)
+  int replan_n[8]; // replanning work queue: [0..3] class list lengths, [4] pool-full retries, [5] queue cursor, [6] entries this rank planned
   unsigned long long pool_used;  // words handed out from the path pool (device-side bump allocator)
   long long astar_calls, astar_exp, astar_relax;
   int pend_n[2];   // lengths of the two ping-pong lists of still-unresolved schedule slots
   unsigned int rng_event;   // first (vehicle index * 2 + is_collision) whose draw fired this pass, 0xFFFFFFFF = none
   unsigned int rng_tot[2];  // pass 1 totals: fixed words, number of speed rolls
   int pad_;
+  int dbg[8];      // debugging aid: first watchdog that fired inside a replanning kernel (code, vehicle index, values)
 };
 
 // Everything the hot kernels read or write about one grid cell, in one 32-byte sector: the four move-phase claim
@@ -63,6 +64,7 @@ __host__ __device__ __forceinline__ int st_road_type(uint8_t s) { return (s >> 6
 
 struct Dev {
   int W, H, N;
+  int W8, H8;                   // the map in 8 x 8 tiles (tiled order of the A* snapshot and tables, see tix)
   unsigned long long w_magic;   // floor(2^40 / W) + 1: y = (cell * w_magic) >> 40 is exact for cell < 2^26, W < 2^14
   double elapsed;   // DynamicTrafficAgent.elapsed as the decide phase sees it (before the clock agent steps)
   Cell* cell;
@@ -86,8 +88,10 @@ struct Dev {
   int32_t* ax_start[4];
   uint32_t* ax_off[4];
   int32_t* ax_len[4];
-  uint8_t* reach;    // per vehicle, this tick: 0 = unknown, 1 = target reachable under strict rules, 2 = not
-  uint8_t* tier_hint;  // per vehicle: the replanning stage (0 = LDS, 1.. = HBM tiers) its last search fitted in
+  uint8_t* tier_hint;  // per vehicle: cost class (0..3) of its last replan, orders the replanning work queue
+  // what a search reads about a cell, as of the last tick start (or the last ensure_amap): static byte | occupied << 8 |
+  // red << 9, in tiled order - one 128-byte line per 8 x 8 tile
+  uint16_t* amap;
   float* density;    // _update_density_map (city_model.py:1764-1778), materialised on demand
   int8_t* occ_snap;  // occupancy at the last tick start (what density_map is a function of)
   // ordered lists
@@ -121,6 +125,7 @@ struct Dev {
   uint32_t* words;      // ring mirror of the global MT19937 stream (tempered words), index = absolute & WORDS_MASK
   uint32_t *Cx, *rollrank, *rollD, *Tcum;
   DevCnt* cnt;
+  volatile int* hdbg;   // debugging aid: progress markers in pinned host memory (TS_KDEBUG builds)
 };
 
 __device__ __forceinline__ int path_dir(const uint32_t* pool, uint32_t off, int k) {
@@ -135,6 +140,10 @@ __device__ __forceinline__ void set_stop(const Dev& d, int c, int8_t v) { d.cell
 __device__ __forceinline__ void cell_xy(const Dev& d, int cell, int& x, int& y) {
   if (d.w_magic) { y = (int)(((unsigned long long)(unsigned)cell * d.w_magic) >> 40); x = cell - y * d.W; }
   else { y = cell / d.W; x = cell - y * d.W; }
+}
+// position of cell (x, y) in the 8 x 8-tiled order
+__device__ __forceinline__ uint32_t tix(const Dev& d, int x, int y) {
+  return ((((uint32_t)(y >> 3) * (uint32_t)d.W8 + (uint32_t)(x >> 3)) << 6) | (uint32_t)((y & 7) << 3) | (uint32_t)(x & 7));
 }
 __device__ __forceinline__ uint32_t claim_rank(uint32_t v, uint32_t prefix) {
   return (v >> RANK_BITS) == prefix ? (v & RANK_MASK) : NO_RANK;

@@ -25,6 +25,7 @@
 #include <condition_variable>
 #include <unordered_map>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/trafficsim.h"
 #include "mt19937.h"
@@ -38,79 +39,62 @@
 
 namespace {
 
-// k_decide_replan over the work lists.  Stage 0 keeps the search structures in LDS (one wave per vehicle), stages
-// 1-4 are the HBM tiers; a search that outgrows its stage moves to the next one, and k_decide_main queues every
-// vehicle directly on the stage its last search fitted in (Dev::tier_hint).
-// Lists: 0 / 4 / 1 / 2 / 5 = input of stages 0..4, 3 = pool-full retries.  Counters (replan_n): 0 / 5 / 1 / 2 / 6 for
-// those inputs, 3 = retries, 4 = beyond the last tier (an error).
-struct ReplanStage { int tier; int in_list; int in_counter; int out_list; int out_counter; };
-static const ReplanStage REPLAN_STAGES[5] = {{-1, 0, 0, 4, 5}, {0, 4, 5, 1, 1}, {1, 1, 1, 2, 2}, {2, 2, 2, 5, 6}, {3, 5, 6, 3, 4}};
-inline int replan_pending(const int* n8) { return n8[0] + n8[5] + n8[1] + n8[2] + n8[6]; }
+// The replanning work queue (k_replan): replan_n[0..3] = class list lengths as k_decide_main left them (e->hint[8..]),
+// lists 0..3 = the classes, list 4 = entries that found the path pool full.
+inline int replan_pending(const int* n8) { return n8[0] + n8[1] + n8[2] + n8[3]; }
 
 int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   Dev& d = e->d;
   const TsParams& P = e->P;
   hipStream_t st = e->stream;
-  StageCaps caps;
-  caps.nodes[0] = LDS_NODES;
-  {
-    const long long N = e->N;
-    const long long c[4] = {std::min<long long>(N, 2048), std::min<long long>(N, 32768), std::min<long long>(N, 262144), N};
-    for (int t = 0; t < 4; t++) caps.nodes[t + 1] = (int)c[t];
-  }
+  RLists rl;
+  for (int q = 0; q < 6; q++) rl.l[q] = e->replan_list[q];
+  int rc = ensure_slots(e);
+  if (rc) return rc;
+  rc = ensure_amap(e);
+  if (rc) return rc;
+  if (!e->density_valid) { rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
   while (replan_pending(e->hint + 8) > 0) {
-    if (!e->density_valid) { int rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
-    {  // strict reachability of every replanner's target (skips the searches that would flood and fail)
-      const size_t words_per = ((size_t)e->N + 31) / 32, queue_per = (size_t)e->N;
-      if (!e->bfs_visited) {
-        size_t per = words_per * 4 + queue_per * 4;
-        e->bfs_slots = (int)std::max<size_t>(8, std::min<size_t>(2048, (3ull << 30) / per));
-        HIPOK(dalloc(e, &e->bfs_visited, words_per * e->bfs_slots));
-        HIPOK(dalloc(e, &e->bfs_queue, queue_per * e->bfs_slots));
-      }
-      for (const ReplanStage& sg : REPLAN_STAGES) {
-        const int n_in = e->hint[8 + sg.in_counter];
-        for (int begin = 0; begin < n_in; begin += e->bfs_slots) {
-          int cnt = std::min(e->bfs_slots, n_in - begin);
-          LAUNCH(e, PK_REACH, cnt, k_reach_strict, dim3(cnt), dim3(64), d, e->replan_list[sg.in_list] + begin, cnt, e->bfs_visited,
-                 e->bfs_queue, words_per, queue_per);
+    const int n = replan_pending(e->hint + 8);
+    const int grid = std::min(n, e->slots.n_slots);
+    LAUNCH(e, PK_REPLAN, n, k_replan, dim3(grid), dim3(64), d, P, e->slots, rl, e->replan_list[4], e->dist_rank, e->dist_world,
+           e->dist_world > 1 ? e->owned_list : nullptr);
+    const double tl = now_ms();
+    if (getenv("TS_DEBUG_POLL") && d.hdbg) {   // watch the kernel: after 8 s without completion print the progress markers and stop
+      const double t0 = now_ms();
+      while (hipStreamQuery(st) == hipErrorNotReady) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        if (now_ms() - t0 > 8000.0) {
+          for (int b = 0; b < 8; b++)
+            fprintf(stderr, "[poll] wg %d: at=%d j=%d i=%d r=%d iter=%d heap=%d start=%d goal=%d\n", b, d.hdbg[b * 8], d.hdbg[b * 8 + 1], d.hdbg[b * 8 + 2],
+                    d.hdbg[b * 8 + 3], d.hdbg[b * 8 + 4], d.hdbg[b * 8 + 5], d.hdbg[b * 8 + 6], d.hdbg[b * 8 + 7]);
+          fflush(stderr);
+          _exit(3);
         }
       }
     }
-    for (int sidx = 0; sidx < 5; sidx++) {
-      const ReplanStage& sg = REPLAN_STAGES[sidx];
-      const int n = e->hint[8 + sg.in_counter];   // hinted entries plus what the previous stage overflowed
-      if (n <= 0) continue;
-      const int t = sg.tier < 0 ? 0 : sg.tier;   // the LDS stage borrows the first tier's cell buffers
-      int rc = ensure_tier(e, t);
-      if (rc) return rc;
-      const ATier& T = e->tier[t];
-      for (int begin = 0; begin < n; begin += T.n_slots) {
-        int cnt = std::min(T.n_slots, n - begin);
-        if (sg.tier < 0)
-          LAUNCH(e, PK_REPLAN, cnt, k_decide_replan_lds, dim3(cnt), dim3(64), d, P, T, e->replan_list[sg.in_list], begin, cnt,
-                 e->replan_list[sg.out_list], sg.out_counter, e->replan_list[3], caps);
-        else
-          LAUNCH(e, PK_REPLAN, cnt, k_decide_replan, dim3(cnt), dim3(64), d, P, T, e->replan_list[sg.in_list], begin,
-                 cnt, e->replan_list[sg.out_list], sg.out_counter, e->replan_list[3], sidx, caps);
-      }
-      const double tl = now_ms();
-      HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
-      HIPOK(hipStreamSynchronize(st));
-      if (e->hint[8 + 4] > 0) return fail(e, TS_E_CAPACITY, "an A* search exceeded the largest scratch tier");
-      if (getenv("TS_DEBUG_REPLAN"))
-        fprintf(stderr, "[replan] tick %lld stage %d: in=%d overflow=%d retry=%d wait=%.2f ms\n", (long long)e->C.step_count, sidx, n,
-                sidx < 4 ? e->hint[8 + sg.out_counter] - 0 : 0, e->hint[8 + 3], now_ms() - tl);
+    HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+    HIPOK(hipMemcpyAsync(e->hint + 3, &d.cnt->error, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    if (getenv("TS_DEBUG_REPLAN")) {
+      int dbg[8];
+      HIPOK(hipMemcpy(dbg, d.cnt->dbg, sizeof(dbg), hipMemcpyDeviceToHost));
+      if (dbg[0]) fprintf(stderr, "[replan] watchdog %d: %d %d %d %d %d %d %d\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
     }
-    const int retry = e->hint[8 + 3];
+    if (e->hint[3] == TS_E_CAPACITY) return fail(e, TS_E_CAPACITY, "an A* search exceeded its heap or path buffers");
+    const int retry = e->hint[8 + 4];
+    if (getenv("TS_DEBUG_REPLAN"))
+      fprintf(stderr, "[replan] tick %lld: %d entries (classes %d/%d/%d/%d) on %d searchers, retry=%d, %.2f ms\n", (long long)e->C.step_count,
+              n, e->hint[8], e->hint[9], e->hint[10], e->hint[11], grid, retry, now_ms() - tl);
     if (retry == 0) break;
     // the path pool filled up: make room (GC, then growth) and run the entries that could not commit again
-    int rc = pool_make_room(e, (size_t)retry * 1024 + (1u << 20));
+    rc = pool_make_room(e, (size_t)retry * 1024 + (1u << 20));
     if (rc) return rc;
-    HIPOK(hipMemcpyAsync(e->replan_list[0], e->replan_list[3], (size_t)retry * 4, hipMemcpyDeviceToDevice, st));
-    HIPOK(hipMemsetAsync(d.cnt->replan_n, 0, sizeof(int) * 8, st));
+    HIPOK(hipMemcpyAsync(e->replan_list[0], e->replan_list[4], (size_t)retry * 4, hipMemcpyDeviceToDevice, st));
+    const int keep_owned = e->hint[8 + 6];
     for (int q = 0; q < 8; q++) e->hint[8 + q] = 0;
-    e->hint[8] = retry;
+    e->hint[8] = retry; e->hint[8 + 6] = keep_owned;
+    HIPOK(hipMemcpyAsync(d.cnt->replan_n, e->hint + 8, sizeof(int) * 8, hipMemcpyHostToDevice, st));
   }
   return TS_OK;
 }
@@ -151,6 +135,7 @@ int tick(E* e) {
   // density_map is a function of the occupancy at this point (city_model.py:1853)
   HIPOK(hipMemcpyAsync(d.occ_snap, d.occ, (size_t)e->N, hipMemcpyDeviceToDevice, st));
   e->density_valid = false;
+  e->amap_valid = false;   // the A* snapshot is rebuilt from the cell records when the first search of the tick needs it
   d.elapsed = e->C.elapsed;
   const bool svc_on = !e->svc.empty();
   int arr_read = 0;   // service records of this tick consumed so far
@@ -528,6 +513,7 @@ int tick(E* e) {
       HIPOK(hipMemsetAsync(d.cnt->pend_n, 0, sizeof(int) * 2, st));
       while (done < target) {
         const int chunk = round_no == 0 ? 1 : 4;
+        e->amap_valid = false;   // the rounds below move vehicles and switch lights
         for (int rr = 0; rr < chunk; rr++, round_no++) {
           if ((e->epoch % EPOCHS) == 0) {  // epoch prefix wrapped: stale keys would win again -> clear once
             size_t n = (size_t)e->N;
@@ -658,6 +644,7 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   e->W = w->width; e->H = w->height; e->N = w->width * w->height;
   Dev& d = e->d;
   d.W = e->W; d.H = e->H; d.N = e->N;
+  d.W8 = (e->W + 7) / 8; d.H8 = (e->H + 7) / 8;
   d.w_magic = (!getenv("TS_NO_MAGIC") && e->W < (1 << 14) && (long long)e->N <= (1ll << 26)) ? ((1ull << 40) / (unsigned long long)e->W + 1ull) : 0ull;
   size_t N = e->N;
   auto bail = [&](int code) { ts_destroy(e); return code; };
@@ -694,6 +681,7 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   ok &= hipMemcpyAsync(e->d_crc, table, sizeof(table), hipMemcpyHostToDevice, st) == hipSuccess;
   ok &= hipHostMalloc((void**)&e->hcnt, sizeof(DevCnt)) == hipSuccess;
   ok &= hipHostMalloc((void**)&e->hint, sizeof(int) * 16) == hipSuccess;
+  { int* hd = nullptr; ok &= hipHostMalloc((void**)&hd, sizeof(int) * 64) == hipSuccess; if (hd) memset(hd, 0, sizeof(int) * 64); d.hdbg = hd; }
   ok &= hipStreamSynchronize(st) == hipSuccess;
   (void)hipFree(t_allowed); (void)hipFree(t_road_type); (void)hipFree(t_inter);
   if (!ok) return bail(TS_E_DEVICE);
@@ -1034,7 +1022,7 @@ static int add_vehicles_core(ts_handle e, int n, std::vector<int32_t>& start, st
   HIPOK(hipMemsetAsync(e->d_total, 0, sizeof(int), st));
   SpawnArgs a{ds, dg, dp, dl, dof, dser};
   hipLaunchKernelGGL(k_spawn, dim3(nblk(n)), dim3(BLK), 0, st, e->d, e->P, a, n, e->n_vehicles_total, e->n_active,
-                     e->n_sched, e->C.elapsed, e->d_overflow, e->d_total);
+                     e->n_sched, e->C.elapsed, e->d_overflow, e->d_total, (e->d.amap && e->amap_valid) ? 1 : 0);
   HIPOK(hipMemcpyAsync(e->hint, e->d_total, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPOK(hipStreamSynchronize(st));
   if (e->hint[0] > 0) hipLaunchKernelGGL(k_spawn_serial, dim3(1), dim3(64), 0, st, e->d, e->d_overflow, e->hint[0]);
@@ -1065,13 +1053,6 @@ static int add_vehicle_planned(ts_handle e, int start, int goal, int pop_type) {
   return plan_vehicle(e, e->n_vehicles_total - 1, start, goal);
 }
 
-// A search that runs alone gains nothing from a small scratch tier (tiers only buy concurrency), and one that outgrows
-// its tier is run again from scratch: start where a search between these two cells very likely fits.
-static int first_tier_for(ts_handle e, int start, int goal) {
-  const int md = std::abs(start % e->W - goal % e->W) + std::abs(start / e->W - goal / e->W);
-  return md < 48 ? 0 : md < 400 ? 1 : md < 2500 ? 2 : 3;
-}
-
 // self.path = self._compute_path() for a vehicle standing on `start` with target `goal` (both already on the
 // device): city._path_cache first, then the phase 0-4 planner on the maps as they are now
 static int plan_vehicle(ts_handle e, int vid, int start, int goal) {
@@ -1095,37 +1076,35 @@ static int plan_vehicle(ts_handle e, int vid, int start, int goal) {
     }
   }
   if (!e->density_valid) { rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
-  for (int t = first_tier_for(e, start, goal); t < ts_engine::N_TIERS; t++) {
-    rc = ensure_tier(e, t);
+  rc = ensure_slots(e);
+  if (rc) return rc;
+  rc = ensure_amap(e);
+  if (rc) return rc;
+  for (int attempt = 0; attempt < 3; attempt++) {
+    hipLaunchKernelGGL(k_spawn_plan, dim3(1), dim3(64), 0, e->stream, d, e->P, e->slots, vid, e->d_status);
+    HIPOK(hipMemcpyAsync(e->hint, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPOK(hipStreamSynchronize(e->stream));
+    if (e->hint[0] != -2) break;
+    rc = pool_make_room(e, (size_t)e->slots.cap + (1u << 16));  // pool full: make room and plan again
     if (rc) return rc;
-    for (int attempt = 0; attempt < 3; attempt++) {
-      hipLaunchKernelGGL(k_spawn_plan, dim3(1), dim3(64), 0, e->stream, d, e->P, e->tier[t], vid, e->d_status);
-      HIPOK(hipMemcpyAsync(e->hint, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-      HIPOK(hipStreamSynchronize(e->stream));
-      if (e->hint[0] != -2) break;
-      rc = pool_make_room(e, (size_t)e->tier[t].cap + (1u << 16));  // pool full: make room and plan again
-      if (rc) return rc;
-    }
-    if (e->hint[0] == -2) return fail(e, TS_E_CAPACITY, "path pool exhausted while planning a spawn");
-    if (e->hint[0] >= 0) {
-      const int len = e->hint[0];
-      rc = pool_from_device(e);
-      if (rc) return rc;
-      uint16_t fl = 0;
-      HIPOK(hipMemcpy(&fl, d.flags + vid, 2, hipMemcpyDeviceToHost));
-      if (e->P.pathfinding_cache && len > 0 && !(fl & (VF_OVER | VF_DETOUR))) {
-        ts_engine::CachedPath cp;
-        cp.len = len;
-        cp.words.resize((size_t)(len + 15) / 16);
-        uint32_t off = 0;
-        HIPOK(hipMemcpy(&off, d.path_off + vid, 4, hipMemcpyDeviceToHost));
-        HIPOK(hipMemcpy(cp.words.data(), d.pool + off, cp.words.size() * 4, hipMemcpyDeviceToHost));
-        e->path_cache[key] = std::move(cp);
-      }
-      return TS_OK;
-    }
   }
-  return fail(e, TS_E_CAPACITY, "an A* search exceeded the largest scratch tier");
+  if (e->hint[0] == -2) return fail(e, TS_E_CAPACITY, "path pool exhausted while planning a spawn");
+  if (e->hint[0] < 0) return fail(e, TS_E_CAPACITY, "an A* search exceeded its heap or path buffers");
+  const int len = e->hint[0];
+  rc = pool_from_device(e);
+  if (rc) return rc;
+  uint16_t fl = 0;
+  HIPOK(hipMemcpy(&fl, d.flags + vid, 2, hipMemcpyDeviceToHost));
+  if (e->P.pathfinding_cache && len > 0 && !(fl & (VF_OVER | VF_DETOUR))) {
+    ts_engine::CachedPath cp;
+    cp.len = len;
+    cp.words.resize((size_t)(len + 15) / 16);
+    uint32_t off = 0;
+    HIPOK(hipMemcpy(&off, d.path_off + vid, 4, hipMemcpyDeviceToHost));
+    HIPOK(hipMemcpy(cp.words.data(), d.pool + off, cp.words.size() * 4, hipMemcpyDeviceToHost));
+    e->path_cache[key] = std::move(cp);
+  }
+  return TS_OK;
 }
 
 static int add_vehicles_any(ts_handle e, int32_t n, const int32_t* start_xy, const int32_t* goal_xy,
@@ -1208,6 +1187,7 @@ int ts_upload_map(ts_handle e, int32_t which, const int8_t* src) {
   int8_t* m = which == TS_MAP_STOP ? e->d.stop : which == TS_MAP_RAIN ? e->d.rain : nullptr;
   if (!m) return fail(e, TS_E_INVALID, "only stop_map and rain_map are host-writable");
   HIPOK(hipMemcpy(m, src, e->N, hipMemcpyHostToDevice));
+  e->amap_valid = false;
   if (which == TS_MAP_STOP) {
     hipLaunchKernelGGL(k_plane_to_cells, dim3(nblk((long long)e->N)), dim3(BLK), 0, e->stream, e->d.cell, e->N, e->d.stop, 1);
     HIPOK(hipStreamSynchronize(e->stream));
@@ -1217,6 +1197,7 @@ int ts_upload_map(ts_handle e, int32_t which, const int8_t* src) {
 int ts_debug_set_occupancy(ts_handle e, const int8_t* src) {
   if (!e || !src) return TS_E_INVALID;
   HIPOK(hipMemcpy(e->d.occ, src, e->N, hipMemcpyHostToDevice));
+  e->amap_valid = false;
   hipLaunchKernelGGL(k_plane_to_cells, dim3(nblk((long long)e->N)), dim3(BLK), 0, e->stream, e->d.cell, e->N, e->d.occ, 0);
   HIPOK(hipStreamSynchronize(e->stream));
   return TS_OK;
@@ -1424,27 +1405,30 @@ int ts_astar(ts_handle e, int32_t sx, int32_t sy, int32_t gx, int32_t gy, int32_
   if (!e) return TS_E_INVALID;
   if (sx < 0 || sx >= e->W || sy < 0 || sy >= e->H || gx < 0 || gx >= e->W || gy < 0 || gy >= e->H)
     return fail(e, TS_E_INVALID, "astar endpoints out of bounds");
+  if (maximum_steps < e->N && maximum_steps > A_STEPS_MAX)
+    return fail(e, TS_E_UNSUPPORTED, "a binding maximum_steps above 4094 is not carried (use >= width * height for 'unlimited')");
   int rc = ensure_density(e, e->d.occ);  // "evaluated on the engine's current maps"
   if (rc) return rc;
   e->density_valid = false;
-  for (int t = first_tier_for(e, sy * e->W + sx, gy * e->W + gx); t < ts_engine::N_TIERS; t++) {
-    rc = ensure_tier(e, t);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_astar_single, dim3(1), dim3(64), 0, e->stream, e->d, e->P, e->tier[t], sy * e->W + sx,
-                       gy * e->W + gx, soft, ignore_flow, maximum_steps, e->d_status);
-    HIPOK(hipMemcpyAsync(e->hint, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPOK(hipStreamSynchronize(e->stream));
-    int len = e->hint[0];
-    if (len < 0) continue;
-    if (len > cap_cells) return TS_E_CAPACITY;
-    if (len > 0) {
-      std::vector<int32_t> cells(len);
-      HIPOK(hipMemcpy(cells.data(), e->tier[t].cells, (size_t)len * 4, hipMemcpyDeviceToHost));
-      for (int k = 0; k < len; k++) { out_xy[2 * k] = cells[k] % e->W; out_xy[2 * k + 1] = cells[k] / e->W; }
-    }
-    return len;
+  rc = ensure_slots(e);
+  if (rc) return rc;
+  e->amap_valid = false;
+  rc = ensure_amap(e);
+  if (rc) return rc;
+  e->amap_valid = false;
+  hipLaunchKernelGGL(k_astar_single, dim3(1), dim3(64), 0, e->stream, e->d, e->P, e->slots, sy * e->W + sx, gy * e->W + gx, soft,
+                     ignore_flow, maximum_steps, e->d_status);
+  HIPOK(hipMemcpyAsync(e->hint, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  const int len = e->hint[0];
+  if (len < 0) return fail(e, TS_E_CAPACITY, "an A* search exceeded its heap or path buffers");
+  if (len > cap_cells) return TS_E_CAPACITY;
+  if (len > 0) {
+    std::vector<int32_t> cells(len);
+    HIPOK(hipMemcpy(cells.data(), e->slots.cells, (size_t)len * 4, hipMemcpyDeviceToHost));
+    for (int k = 0; k < len; k++) { out_xy[2 * k] = cells[k] % e->W; out_xy[2 * k + 1] = cells[k] / e->W; }
   }
-  return fail(e, TS_E_CAPACITY, "an A* search exceeded the largest scratch tier");
+  return len;
 }
 
 }  // extern "C"

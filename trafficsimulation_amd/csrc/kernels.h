@@ -634,7 +634,7 @@ struct SpawnArgs {
   const uint8_t* serial;  // 1 = start cell shared inside the batch -> placed by the serial kernel
 };
 __global__ void k_spawn(Dev d, TsParams P, SpawnArgs a, int n, int vid0, int active0, int sched0, double elapsed,
-                        int* overflow, int* n_overflow) {
+                        int* overflow, int* n_overflow, int amap_live) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int vid = vid0 + i;
@@ -646,6 +646,12 @@ __global__ void k_spawn(Dev d, TsParams P, SpawnArgs a, int n, int vid0, int act
   d.base_speed[vid] = 0; d.cur_speed[vid] = 0; d.max_steps[vid] = 0; d.dir[vid] = -1; d.pop[vid] = (int8_t)a.pop[i];
   d.flags[vid] = VF_ALIVE; d.depart[vid] = P.enable_traffic ? elapsed : 0.0;
   d.ev[vid] = 0; d.st_before[vid] = 0; d.st_after[vid] = 0; d.tier_hint[vid] = 0;
+  if (amap_live) {   // keep the A* snapshot current: the spawn-time planners of this batch run on it
+    int x, y;
+    cell_xy(d, pos, x, y);
+    const uint32_t t = tix(d, x, y);
+    atomicOr(reinterpret_cast<unsigned int*>(d.amap) + (t >> 1), 0x100u << ((t & 1) * 16));
+  }
   for (int k = 0; k < 4; k++) { d.ax_len[k][vid] = 0; d.ax_off[k][vid] = 0; d.ax_start[k][vid] = pos; }
   d.active[active0 + i] = vid; d.active_idx[vid] = active0 + i;
   d.sched_kind[sched0 + i] = K_VEHICLE; d.sched_ref[sched0 + i] = vid; d.sched_slot[vid] = sched0 + i;
@@ -781,6 +787,15 @@ __global__ void k_cells_init(Cell* cell, int n, const uint8_t* allowed, const in
   x.stat = (uint8_t)((allowed[c] & 15) | ((is_road[c] == 1) << 4) | ((inter[c] == 1) << 5) | ((road_type[c] & 3) << 6));
   x.pad_[0] = x.pad_[1] = 0;
   cell[c] = x;
+}
+// the A* snapshot of the maps (Dev::amap) from the cell records
+__global__ void k_amap_build(Dev d) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d.N) return;
+  int x, y;
+  cell_xy(d, c, x, y);
+  const uint32_t dw = *reinterpret_cast<const uint32_t*>(&d.cell[c].occ);   // occ | stop << 8 | stuck << 16 | stat << 24
+  d.amap[tix(d, x, y)] = (uint16_t)((dw >> 24) | (((int8_t)(dw & 0xFF) == 1) ? 0x100u : 0u) | (((int8_t)((dw >> 8) & 0xFF) == 1) ? 0x200u : 0u));
 }
 __global__ void k_claims_reset(Cell* cell, int n) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
