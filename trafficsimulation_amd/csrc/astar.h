@@ -47,7 +47,7 @@ struct __attribute__((aligned(8))) TEnt { int32_t dist; uint32_t meta; };   // m
 constexpr uint32_t T_STAMP_SHIFT = 14, T_STEPS_MASK = 0xFFF, T_STAMP_MAX = (1u << 18) - 1;
 constexpr int A_STEPS_MAX = (int)T_STEPS_MASK - 1;   // largest binding step limit a search can carry (a limit >= N never binds)
 
-__shared__ HQ g_lq[LDS_HEAP];
+__shared__ unsigned long long g_lq[LDS_HEAP];   // packed HQ: f in the low word, cell in the high word
 __shared__ int8_t g_ld[LDS_HEAP];
 __shared__ int g_job;   // k_replan: the work-queue entry the wave is on
 
@@ -106,11 +106,47 @@ __device__ __forceinline__ double rl(double v, int lane) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// heap slot k / its dir byte: LDS below LDS_HEAP, the searcher's HBM spill above (gq / gd are the slot's spill arrays)
-__device__ __forceinline__ HQ hq_get(const HQ* gq, int k) { return k < LDS_HEAP ? g_lq[k] : gq[k - LDS_HEAP]; }
-__device__ __forceinline__ void hq_put(HQ* gq, int k, HQ v) { if (k < LDS_HEAP) g_lq[k] = v; else gq[k - LDS_HEAP] = v; }
-__device__ __forceinline__ int hd_get(const int8_t* gd, int k) { return k < LDS_HEAP ? (int)g_ld[k] : (int)gd[k - LDS_HEAP]; }
-__device__ __forceinline__ void hd_put(int8_t* gd, int k, int v) { if (k < LDS_HEAP) g_ld[k] = (int8_t)v; else gd[k - LDS_HEAP] = (int8_t)v; }
+// Heap entries and table records travel as packed 64-bit words (HQ: f low, cell high; TEnt: dist low, meta high), and
+// the searcher's HBM arrays are addressed through global-address-space pointers: pointers that reach a function inside
+// a struct are generic to the compiler, and generic ("flat") loads count against the LDS wait counter as well, which
+// would make every LDS wait of the sift-down also wait for the expansion's loads in flight.
+#define TS_GLOBAL __attribute__((address_space(1)))
+typedef unsigned long long u64;
+typedef TS_GLOBAL u64* gu64p;
+typedef TS_GLOBAL int8_t* gi8p;
+typedef TS_GLOBAL int32_t* gi32p;
+__device__ __forceinline__ u64 hq_pack(int f, int i) { return (u64)(uint32_t)f | ((u64)(uint32_t)i << 32); }
+__device__ __forceinline__ int hq_f(u64 e) { return (int)(uint32_t)e; }
+__device__ __forceinline__ int hq_i(u64 e) { return (int)(uint32_t)(e >> 32); }
+__device__ __forceinline__ u64 rl(u64 v, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 uni64(u64 v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((u64)hi << 32) | lo;
+}
+// heap slot k / its dir byte: LDS below LDS_HEAP, the searcher's HBM spill above (gq / gd are the slot's spill arrays).
+// SPILL = false: the caller guarantees k < LDS_HEAP - straight LDS accesses, no branch (and with it no conservative
+// wait for the expansion's loads in flight) in the hot loop.
+template <bool SPILL> __device__ __forceinline__ u64 hq_get(gu64p gq, int k) {
+  if constexpr (SPILL) return k < LDS_HEAP ? g_lq[k] : gq[k - LDS_HEAP];
+  else return g_lq[k];
+}
+template <bool SPILL> __device__ __forceinline__ void hq_put(gu64p gq, int k, u64 v) {
+  if constexpr (SPILL) { if (k < LDS_HEAP) g_lq[k] = v; else gq[k - LDS_HEAP] = v; }
+  else g_lq[k] = v;
+}
+template <bool SPILL> __device__ __forceinline__ int hd_get(gi8p gd, int k) {
+  if constexpr (SPILL) return k < LDS_HEAP ? (int)g_ld[k] : (int)gd[k - LDS_HEAP];
+  else return (int)g_ld[k];
+}
+template <bool SPILL> __device__ __forceinline__ void hd_put(gi8p gd, int k, int v) {
+  if constexpr (SPILL) { if (k < LDS_HEAP) g_ld[k] = (int8_t)v; else gd[k - LDS_HEAP] = (int8_t)v; }
+  else g_ld[k] = (int8_t)v;
+}
 
 // a fresh epoch for the searcher's table (cleared by the wave when the 18-bit stamp wraps)
 __device__ __forceinline__ uint32_t next_epoch(const Dev& d, AScratch& S) {
@@ -123,206 +159,267 @@ __device__ __forceinline__ uint32_t next_epoch(const Dev& d, AScratch& S) {
   return ++S.epoch;
 }
 
+// what a search keeps in registers while its loop runs (d, P and S themselves live in scratch memory behind references)
+struct ACtx {
+  int W, H, W8, N, lane;
+  u64 w_magic;
+  gu64p gq, tab;
+  gi8p gd;
+  const TS_GLOBAL uint16_t* amap;
+  const TS_GLOBAL float* density;
+  gi32p outg;
+  int heap_cap, out_cap, start_idx, goal_idx, gx, gy, maximum_steps;
+  uint32_t epoch;
+  bool soft, ignore_flow, limited, turn_on, rt_on, dens_on;
+  double turn_pen, contra_pen, veh_pen, stop_pen, dyn_scale, rt1, rt2, rt3;
+  long long n_exp, n_relax;
+  __device__ __forceinline__ void xy_of(int cell, int& x, int& y) const {
+    if (w_magic) { y = (int)(((u64)(unsigned)cell * w_magic) >> 40); x = cell - y * W; }
+    else { y = cell / W; x = cell - y * W; }
+  }
+  __device__ __forceinline__ uint32_t tile_ix(int x, int y) const {
+    return ((((uint32_t)(y >> 3) * (uint32_t)W8 + (uint32_t)(x >> 3)) << 6) | (uint32_t)((y & 7) << 3) | (uint32_t)(x & 7));
+  }
+};
+enum { AL_EMPTY = -2, AL_OVERFLOW = -1, AL_SWITCH = -3 };   // astar_loop results besides a path length >= 0
+
 // ---------------------------------------------------------------------------------------------
-// astar_core, one search spread over one wavefront.  All 64 lanes call it with identical arguments and get the
-// same return value.  The algorithm is the sequential one - same heap layout, same comparisons, same order of
-// relaxations - only its memory traffic is organised by lanes:
-//   * sift-down: the 62 entries of the next five levels below the hole are fetched at once (one per lane) and the
-//     walk down those levels reads them with cross-lane reads;
+// astar_core's main loop, one search spread over one wavefront.  The algorithm is the sequential one - same heap
+// layout, same comparisons, same order of relaxations - only its work is organised by lanes:
+//   * everything the expansion of the popped cell reads from HBM is requested as soon as the cell is known (lanes
+//     0-3: map entry, table record and density of neighbour `lane`; the other lanes: the cell's own) and travels while
+//     the sift-down works on the heap;
+//   * sift-down: lanes 2..63 fetch the 62 entries of the five levels below the hole at once (lane L's children sit
+//     on lanes 2L and 2L + 1, siblings on an even / odd lane pair); every lane decides with its sibling's key (one DPP
+//     swap) whether its entry would move up if its parent were the hole, one ballot collects that, the walk down
+//     the five levels is scalar bit tests on the ballot, and the entries on the path move up with one masked write;
 //   * sift-up of a push: the ancestors of the new slot are fetched at once, a ballot finds how far the entry rises,
 //     the lanes holding ancestors write them one level down in parallel;
-//   * the four neighbours are prepared on lanes 0-3 (map entry, density, table record; lane 4 holds the popped cell's
-//     own), then committed in the reference's order N, E, S, W.
-// Writes the path (start excluded, goal included) to out[0..len); returns len >= 0, or -1 when the heap or the
-// output buffer is too small.
+//   * the four neighbours are evaluated on lanes 0-3, then committed in the reference's order N, E, S, W.
+// SPILL = false runs while the whole heap fits LDS (straight LDS accesses); SPILL = true is the general form.  Either
+// returns AL_SWITCH when the other one should take over.
 // ---------------------------------------------------------------------------------------------
-__device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int start_idx, int goal_idx, bool soft,
-                          bool ignore_flow, int maximum_steps, int32_t* out, int out_cap) {
-  const int W = d.W, H = d.H;
-  const int lane = lane_id();
-  // the arguments arrive in vector registers: tell the compiler they are wave-uniform (scalar loop control)
-  start_idx = uni(start_idx); goal_idx = uni(goal_idx); maximum_steps = uni(maximum_steps); out_cap = uni(out_cap);
-  soft = uni((int)soft) != 0; ignore_flow = uni((int)ignore_flow) != 0;
-  S.calls++;
-  const uint32_t epoch = (uint32_t)uni((int)next_epoch(d, S));
-  KMARK(6, start_idx); KMARK(7, goal_idx); KMARK(0, 200 + (int)soft * 2 + (int)ignore_flow);
-  // the searcher's arrays and counters in registers for the loop (S itself may live in scratch memory)
-  HQ* const gq = S.gq;
-  int8_t* const gd = S.gd;
-  TEnt* const tab = S.tab;
-  const int heap_cap = uni(S.heap_cap);
-  long long n_exp = 0, n_relax = 0;
-  const uint32_t stamp = epoch << T_STAMP_SHIFT;
-  // the chain of relaxations behind a heap entry never revisits a cell (dist strictly falls), so it is shorter than
-  // N: a limit of N or more never binds and the steps need not be carried
-  const bool limited = maximum_steps < d.N;
-  int gx, gy, sx, sy;
-  cell_xy(d, goal_idx, gx, gy);
-  cell_xy(d, start_idx, sx, sy);
-  if (lane == 0) {
-    tab[tix(d, sx, sy)] = TEnt{0, stamp};
-    g_lq[0] = HQ{abs(sx - gx) + abs(sy - gy), start_idx};
-    g_ld[0] = -1;
-  }
-  int heap_size = 1;
-  wave_mem_sync();
-  // relative position of this lane inside a 63-entry window hanging below a hole: level and offset in the level
-  const int rlvl = 31 - __builtin_clz((unsigned)(lane + 1));   // 0 for lane 0, 1 for 1-2, ... 5 for 31-62
-  const int roff = (lane + 1) - (1 << rlvl);
-  const bool dens_on = soft && P.dynamic_penalties_enabled;
-  long long guard = 0;
+template <bool SPILL>
+__device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
+  // A lone wave issues one instruction every four cycles whatever its kind, so this loop is written for instruction
+  // count: lane-parallel vector work and one ballot in place of scalar walks, no scalar <-> vector round trips that
+  // can be avoided.
+  const int lane = C.lane;
+  const int W = C.W, H = C.H;
+  const gu64p gq = C.gq;
+  const gi8p gd = C.gd;
+  const gu64p tab = C.tab;
+  const uint32_t epoch = C.epoch, stamp = C.epoch << T_STAMP_SHIFT;
+  const int gx = C.gx, gy = C.gy;
+  // window geometry of this lane (lanes 2..63 = the 62 entries of five levels below a hole that sits on "lane 1")
+  const int wlvl = 31 - __builtin_clz((unsigned)max(lane, 1));   // 1 for lanes 2-3, ... 5 for 32-63
+  const int woff = lane - (1 << wlvl);
+  const bool wleft = (lane & 1) == 0;
+  const int dd_l = lane & 3;
+  const int dx_l = lane < 4 ? (dd_l == 1) - (dd_l == 3) : 0, dy_l = lane < 4 ? (dd_l == 0) - (dd_l == 2) : 0;
+  const unsigned below_l = (1u << lane) - 1u;                      // (lanes 0-3 use it)
   while (heap_size > 0) {
-    if ((guard & 1023) == 0) { KMARK(4, (int)guard); KMARK(5, heap_size); }
-    if (++guard > (1ll << 21)) { if (lane == 0 && atomicCAS(&d.cnt->dbg[0], 0, 1) == 0) { d.cnt->dbg[1] = start_idx; d.cnt->dbg[2] = goal_idx; d.cnt->dbg[3] = heap_size; d.cnt->dbg[4] = (int)n_exp; d.cnt->dbg[5] = maximum_steps; d.cnt->dbg[6] = soft * 2 + ignore_flow; d.cnt->dbg[7] = (int)epoch; } return -1; }
-    const HQ top = g_lq[0];
-    const int f_top = uni(top.f), cur = uni(top.i);
+    if (!SPILL && heap_size > LDS_HEAP - 4) return AL_SWITCH;        // this turn's pushes might not fit LDS
+    if (SPILL && heap_size < LDS_HEAP / 2) return AL_SWITCH;
+    const u64 top = g_lq[0];
     const int prev_dir = uni((int)g_ld[0]);
+    const u64 x = uni64(hq_get<SPILL>(gq, heap_size - 1));            // the last entry: it takes the root's place
+    const int xd = uni(hd_get<SPILL>(gd, heap_size - 1));
+    const int f_top = uni(hq_f(top)), cur = uni(hq_i(top));
     heap_size--;
-    // Everything the expansion of `cur` will read from HBM is requested now, so that it travels while the sift-down
-    // below works on the heap: lanes 0-3 the map entry, table record and density of neighbour `lane`, every other
-    // lane those of `cur` itself (lane 4 is the one read back).
     int cx, cy;
-    cell_xy(d, cur, cx, cy);
-    const int dd_l = lane & 3;
-    const int nx_l = lane < 4 ? cx + (dd_l == 1) - (dd_l == 3) : cx, ny_l = lane < 4 ? cy + (dd_l == 0) - (dd_l == 2) : cy;
-    const bool inb_l = nx_l >= 0 && nx_l < W && ny_l >= 0 && ny_l < H;
+    C.xy_of(cur, cx, cy);
+    const int nx_l = cx + dx_l, ny_l = cy + dy_l;
+    const bool inb_l = (unsigned)nx_l < (unsigned)W && (unsigned)ny_l < (unsigned)H;
     const int nidx_l = inb_l ? ny_l * W + nx_l : cur;
-    const uint32_t t_l = inb_l ? tix(d, nx_l, ny_l) : tix(d, cx, cy);
-    const uint32_t a_l = d.amap[t_l];
-    const TEnt e_l = tab[t_l];
-    const float dens_l = dens_on && lane < 4 ? d.density[nidx_l] : 0.f;
+    const uint32_t t_l = inb_l ? C.tile_ix(nx_l, ny_l) : C.tile_ix(cx, cy);
+    const uint32_t a_l = C.amap[t_l];
+    const u64 e_l = tab[t_l];
+    const float dens_l = C.density[nidx_l];      // (read whether or not the search is soft: no branch around a load)
     if (heap_size > 0) {
-      HQ x = hq_get(gq, heap_size);
-      x.f = uni(x.f); x.i = uni(x.i);
-      const int xd = uni(hd_get(gd, heap_size));
+      const int xf = hq_f(x);
       wave_mem_sync();                     // every lane has read slot 0 before it is overwritten
       if (lane == 0) g_ld[0] = (int8_t)xd;
       int idx = 0;                         // the hole; x keeps sinking
-      bool placed = false;
-      int wguard = 0;
-      while (!placed) {
-        if (++wguard > 64) { if (lane == 0 && atomicCAS(&d.cnt->dbg[0], 0, 2) == 0) { d.cnt->dbg[1] = heap_size; d.cnt->dbg[2] = idx; } return -1; }
-        // fetch the window below the hole
-        const int abs_l = ((idx + 1) << rlvl) + roff - 1;
-        const bool in_heap = lane >= 1 && lane <= 62 && abs_l < heap_size;
-        HQ mine = in_heap ? hq_get(gq, abs_l) : HQ{0x7FFFFFFF, 0};
-        int cur_rel = 0, cur_abs = idx;
+      for (;;) {
+        const int abs_l = ((idx + 1) << wlvl) + woff - 1;
+        const bool valid = lane >= 2 && abs_l < heap_size;
+        const u64 mine = hq_get<SPILL>(gq, valid ? abs_l : 0);
+        const int mf = valid ? hq_f(mine) : 0x7FFFFFFF;
+        const int sf = __builtin_amdgcn_mov_dpp(mf, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: the sibling's key
+        // smallest of (x, left, right) with ties going to x, then left (heap_sift_down, astar_numba.py:67-85):
+        // "my entry moves up if my parent is the hole" - at most one of two siblings
+        const bool win = mf < xf && (wleft ? mf <= sf : mf < sf);
+        const unsigned long long wmask = __ballot(win);
+        // follow the winners from the hole (virtual lane 1) down the five levels: scalar, branch-free
+        int L = 1, k = 0;
+        bool alive = true;
 #pragma unroll
         for (int lv = 0; lv < 5; lv++) {
-          const int l_rel = 2 * cur_rel + 1, r_rel = l_rel + 1;
-          const int l_abs = 2 * cur_abs + 1, r_abs = l_abs + 1;
-          if (l_abs >= heap_size) { if (lane == 0) hq_put(gq, cur_abs, x); placed = true; break; }
-          const int lf = rl(mine.f, l_rel), rf = rl(mine.f, r_rel);
-          int smallest = cur_rel, fs = x.f;
-          if (lf < fs) { smallest = l_rel; fs = lf; }
-          if (r_abs < heap_size && rf < fs) smallest = r_rel;
-          if (smallest == cur_rel) { if (lane == 0) hq_put(gq, cur_abs, x); placed = true; break; }
-          if (lane == smallest) hq_put(gq, cur_abs, mine);     // the child moves up
-          cur_abs = smallest == l_rel ? l_abs : r_abs;
-          cur_rel = smallest;
+          const unsigned m = (unsigned)(wmask >> (2 * L)) & 3u;      // the two children of L: at most one bit set
+          alive = alive && m != 0u;
+          L = alive ? 2 * L + (int)(m >> 1) : L;
+          k += alive ? 1 : 0;
         }
-        if (!placed) idx = cur_abs;       // five levels down and still sinking: next window
+        // lanes on the path (levels 1..k, ancestors-or-self of L) hand their entry to the parent's slot
+        if (wlvl >= 1 && wlvl <= k && (L >> (k - wlvl)) == lane) hq_put<SPILL>(gq, (abs_l - 1) >> 1, mine);
+        const int abs_end = ((idx + 1) << k) + (L - (1 << k)) - 1;
+        if (k < 5) { if (lane == 0) hq_put<SPILL>(gq, abs_end, x); break; }
+        idx = abs_end;                     // five levels down and still sinking: next window
       }
     }
     wave_mem_sync();
-    if (cur == goal_idx) {
+    if (cur == C.goal_idx) {
       // walk came_from back to the start, filling the output from its far end, then slide it to the front
-      int len = 0, x = cx, y = cy;
-      for (int c = cur; c != start_idx;) {
-        if (x < 0 || x >= W || y < 0 || y >= H) { if (lane == 0 && atomicCAS(&d.cnt->dbg[0], 0, 3) == 0) { d.cnt->dbg[1] = start_idx; d.cnt->dbg[2] = goal_idx; d.cnt->dbg[3] = len; d.cnt->dbg[4] = x; d.cnt->dbg[5] = y; } return -1; }
-        if (len >= out_cap) { S.expansions += n_exp; S.relaxations += n_relax; return -1; }
-        if (lane == 0) out[out_cap - 1 - len] = c;
+      const gi32p outg = C.outg;
+      const int out_cap = C.out_cap;
+      int len = 0, px = cx, py = cy;
+      for (int c = cur; c != C.start_idx;) {
+        if (len >= out_cap) return AL_OVERFLOW;
+        if (lane == 0) outg[out_cap - 1 - len] = c;
         len++;
-        const int dd = (int)(tab[tix(d, x, y)].meta & 3u);
-        x -= (dd == 1) - (dd == 3); y -= (dd == 0) - (dd == 2);
-        c = y * W + x;
+        const int dd = (int)((tab[C.tile_ix(px, py)] >> 32) & 3u);
+        px -= (dd == 1) - (dd == 3); py -= (dd == 0) - (dd == 2);
+        c = py * W + px;
       }
       __syncthreads();
       const int shift = out_cap - len;
       if (shift > 0)
         for (int k0 = 0; k0 < len; k0 += 64) {
           const int k = k0 + lane;
-          const int v = k < len ? out[shift + k] : 0;
-          if (k < len) out[k] = v;
+          const int v = k < len ? outg[shift + k] : 0;
+          if (k < len) outg[k] = v;
         }
       __syncthreads();
-      S.expansions += n_exp; S.relaxations += n_relax;
-      KDBG("[k] b%d astar found len=%d exp=%lld\n", (int)blockIdx.x, len, n_exp);
       return len;
     }
     const int g = f_top - (abs(cx - gx) + abs(cy - gy));
-    const uint32_t m_c = (uint32_t)rl((int)e_l.meta, 4);
+    const u64 e_c = rl(e_l, 4);
+    const uint32_t m_c = (uint32_t)(e_c >> 32);
     {
-      const int dist_c = (m_c >> T_STAMP_SHIFT) == epoch ? rl(e_l.dist, 4) : A_INF;
+      const int dist_c = (m_c >> T_STAMP_SHIFT) == epoch ? (int)(uint32_t)e_c : A_INF;
       if (g > dist_c) continue;
     }
-    n_exp++;
-    const int steps = limited ? (int)((m_c >> 2) & T_STEPS_MASK) : 0;
-    const uint8_t bits = (uint8_t)st_allowed((uint8_t)((uint32_t)rl((int)a_l, 4) & 0xFF));
-    // ---- prepare: lane dd < 4 evaluates neighbour dd from what was fetched before the sift-down ---------------
-    bool ok_l = lane < 4 && inb_l && steps + 1 <= maximum_steps;
+    C.n_exp++;
+    const int steps = C.limited ? (int)((m_c >> 2) & T_STEPS_MASK) : 0;
+    const uint32_t bits = (uint32_t)rl((int)a_l, 4) & 15u;
+    // ---- lane dd < 4 evaluates neighbour dd from what was fetched before the sift-down -------------------------
+    bool ok_l = lane < 4 && inb_l && steps + 1 <= C.maximum_steps;
     double ng_l = g + 1;
-    const bool found_l = (e_l.meta >> T_STAMP_SHIFT) == epoch;
-    if (ok_l) {
+    {
+      const uint32_t m_l = (uint32_t)(e_l >> 32);
+      const int dist_l = (m_l >> T_STAMP_SHIFT) == epoch ? (int)(uint32_t)e_l : A_INF;
       const int n_occ = (int)((a_l >> 8) & 1u), n_stop = (int)((a_l >> 9) & 1u);
       const uint8_t n_stat = (uint8_t)(a_l & 0xFF);
-      if (P.turn_penalty_enabled && prev_dir != -1 && dd_l != prev_dir) ng_l += P.turn_penalty;
-      if ((bits & (1 << dd_l)) == 0) {
-        if (ignore_flow && st_is_road(n_stat) == 1) ng_l += P.contraflow_penalty;
+      if (C.turn_on && prev_dir != -1 && dd_l != prev_dir) ng_l += C.turn_pen;
+      if ((bits & (1u << dd_l)) == 0) {
+        if (C.ignore_flow && st_is_road(n_stat) == 1) ng_l += C.contra_pen;
         else ok_l = false;
       }
-      if (ok_l && n_occ == 1) {
-        if (soft && P.dynamic_penalties_enabled) {
-          double p = P.obstacle_penalty_vehicle;
+      if (n_occ == 1) {
+        if (C.dens_on) {
           double local_density = (double)dens_l;
-          ng_l += (double)(long long)(p * (1.0 + P.dynamic_penalty_scale * local_density));
-        } else if (soft) ng_l += P.obstacle_penalty_vehicle;
+          ng_l += (double)(long long)(C.veh_pen * (1.0 + C.dyn_scale * local_density));
+        } else if (C.soft) ng_l += C.veh_pen;
         else ok_l = false;
       }
-      if (ok_l && n_stop == 1) {
-        if (soft) ng_l += P.obstacle_penalty_stop;
+      if (n_stop == 1) {
+        if (C.soft) ng_l += C.stop_pen;
         else ok_l = false;
       }
-      if (ok_l && P.road_type_penalties_enabled && st_is_road(n_stat) == 1) {
+      if (C.rt_on && st_is_road(n_stat) == 1) {
         int rt = st_road_type(n_stat);
-        if (rt == 1) ng_l += P.road_type_penalty_r1;
-        else if (rt == 2) ng_l += P.road_type_penalty_r2;
-        else if (rt == 3) ng_l += P.road_type_penalty_r3;
+        if (rt == 1) ng_l += C.rt1;
+        else if (rt == 2) ng_l += C.rt2;
+        else if (rt == 3) ng_l += C.rt3;
       }
-      if (ok_l && !(ng_l < (double)(found_l ? e_l.dist : A_INF))) ok_l = false;
+      if (!(ng_l < (double)dist_l)) ok_l = false;
     }
-    // ---- commit in the reference's order (the four neighbours are distinct cells: no commit changes another's test)
+    // ---- commit.  The four neighbours are distinct cells, so no relaxation changes another one's test: the table
+    // records and the dir bytes of all of them go out with one masked store each; only the heap pushes are made one
+    // after the other, in the reference's order N, E, S, W.
     unsigned relax = (unsigned)(__ballot(ok_l) & 15ull);
+    if (relax == 0u) continue;
+    const int n_new = __builtin_popcount(relax);
+    C.n_relax += n_new;
+    if (heap_size + n_new > C.heap_cap) return AL_OVERFLOW;
+    const int ngi_l = (int)ng_l;
+    const u64 ent_l = hq_pack((int)(ng_l + (double)(abs(nx_l - gx) + abs(ny_l - gy))), nidx_l);
+    if (ok_l) {
+      tab[t_l] = (u64)(uint32_t)ngi_l | ((u64)(stamp | (C.limited ? (uint32_t)(steps + 1) << 2 : 0u) | (uint32_t)dd_l) << 32);
+      hd_put<SPILL>(gd, heap_size + __builtin_popcount(relax & below_l), dd_l);
+    }
     while (relax) {
       const int dd = __builtin_ctz(relax);
       relax &= relax - 1;
-      n_relax++;
-      if (heap_size >= heap_cap) { S.expansions += n_exp; S.relaxations += n_relax; return -1; }
-      const double ng = rl(ng_l, dd);
-      const int nidx = rl(nidx_l, dd), nx = rl(nx_l, dd), ny = rl(ny_l, dd);
-      const uint32_t t_n = (uint32_t)rl((int)t_l, dd);
-      const HQ x{(int)(ng + (double)(abs(nx - gx) + abs(ny - gy))), nidx};
+      const u64 nx64 = rl(ent_l, dd);
+      const int nf = hq_f(nx64);
       const int i = heap_size;
       // ancestors of slot i: a_k = ((i + 1) >> k) - 1, k = 1 .. depth; lane k - 1 fetches a_k
       const int depth = 31 - __builtin_clz((unsigned)(i + 1));
       const bool has = lane < depth;                                  // depth <= 31: lanes beyond it fetch nothing
       const int a_mine = has ? ((i + 1) >> (lane + 1)) - 1 : 0;      // (an unguarded shift by lane + 1 >= 32 is undefined)
-      const HQ anc = has ? hq_get(gq, a_mine) : HQ{(int)0x80000000, 0};
-      const unsigned long long rises = __ballot(has && x.f < anc.f);
+      const u64 anc = hq_get<SPILL>(gq, a_mine);
+      const unsigned long long rises = __ballot(has && nf < hq_f(anc));
       const int r = rises == ~0ull ? 64 : __builtin_ctzll(~rises);      // leading ancestors the entry passes
-      if (lane == 0) {
-        tab[t_n] = TEnt{(int)ng, stamp | (limited ? (uint32_t)(steps + 1) << 2 : 0u) | (uint32_t)dd};
-        hd_put(gd, i, dd);
-      }
-      if (lane < r) hq_put(gq, ((i + 1) >> lane) - 1, anc);             // ancestor k moves to where k - 1 was
-      if (lane == 0) hq_put(gq, ((i + 1) >> r) - 1, x);
+      if (lane < r) hq_put<SPILL>(gq, ((i + 1) >> lane) - 1, anc);      // ancestor k moves to where k - 1 was
+      if (lane == 0) hq_put<SPILL>(gq, ((i + 1) >> r) - 1, nx64);
       heap_size++;
       wave_mem_sync();
     }
   }
-  S.expansions += n_exp; S.relaxations += n_relax;
-  KDBG("[k] b%d astar empty exp=%lld\n", (int)blockIdx.x, n_exp);
-  return 0;
+  return AL_EMPTY;
+}
+
+// astar_core (astar_numba.py:87-239).  All 64 lanes call it with identical arguments and get the same return value.
+// Writes the path (start excluded, goal included) to out[0..len); returns len >= 0, or -1 when the heap or the output
+// buffer is too small.
+__device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int start_idx, int goal_idx, bool soft,
+                          bool ignore_flow, int maximum_steps, int32_t* out, int out_cap) {
+  ACtx C;
+  C.lane = lane_id();
+  // the arguments arrive in vector registers: tell the compiler they are wave-uniform (scalar loop control)
+  C.start_idx = uni(start_idx); C.goal_idx = uni(goal_idx); C.maximum_steps = uni(maximum_steps); C.out_cap = uni(out_cap);
+  C.soft = uni((int)soft) != 0; C.ignore_flow = uni((int)ignore_flow) != 0;
+  S.calls++;
+  C.epoch = (uint32_t)uni((int)next_epoch(d, S));
+  C.W = uni(d.W); C.H = uni(d.H); C.W8 = uni(d.W8); C.N = uni(d.N);
+  C.w_magic = uni64(d.w_magic);
+  C.gq = (gu64p)(uintptr_t)uni64((u64)(uintptr_t)S.gq);
+  C.gd = (gi8p)(uintptr_t)uni64((u64)(uintptr_t)S.gd);
+  C.tab = (gu64p)(uintptr_t)uni64((u64)(uintptr_t)S.tab);
+  C.amap = (const TS_GLOBAL uint16_t*)(uintptr_t)uni64((u64)(uintptr_t)d.amap);
+  C.density = (const TS_GLOBAL float*)(uintptr_t)uni64((u64)(uintptr_t)d.density);
+  C.outg = (gi32p)(uintptr_t)uni64((u64)(uintptr_t)out);
+  C.heap_cap = uni(S.heap_cap);
+  C.turn_on = P.turn_penalty_enabled != 0; C.rt_on = P.road_type_penalties_enabled != 0;
+  C.dens_on = C.soft && P.dynamic_penalties_enabled;
+  C.turn_pen = P.turn_penalty; C.contra_pen = P.contraflow_penalty; C.veh_pen = P.obstacle_penalty_vehicle;
+  C.stop_pen = P.obstacle_penalty_stop; C.dyn_scale = P.dynamic_penalty_scale; C.rt1 = P.road_type_penalty_r1;
+  C.rt2 = P.road_type_penalty_r2; C.rt3 = P.road_type_penalty_r3;
+  C.n_exp = 0; C.n_relax = 0;
+  // the chain of relaxations behind a heap entry never revisits a cell (dist strictly falls), so it is shorter than
+  // N: a limit of N or more never binds and the steps need not be carried
+  C.limited = C.maximum_steps < C.N;
+  int sx, sy;
+  C.xy_of(C.goal_idx, C.gx, C.gy);
+  C.xy_of(C.start_idx, sx, sy);
+  if (C.lane == 0) {
+    C.tab[C.tile_ix(sx, sy)] = (u64)0u | ((u64)(C.epoch << T_STAMP_SHIFT) << 32);    // dist 0, steps 0
+    g_lq[0] = hq_pack(abs(sx - C.gx) + abs(sy - C.gy), C.start_idx);
+    g_ld[0] = -1;
+  }
+  int heap_size = 1;
+  wave_mem_sync();
+  int r;
+  for (;;) {
+    r = astar_loop<false>(C, heap_size);
+    if (r != AL_SWITCH) break;
+    r = astar_loop<true>(C, heap_size);
+    if (r != AL_SWITCH) break;
+  }
+  S.expansions += C.n_exp; S.relaxations += C.n_relax;
+  return r == AL_EMPTY ? 0 : r;
 }
 
 // Strict reachability of `goal` from `start`: a frontier BFS by the wave over the same edges the strict A* relaxes
@@ -331,18 +428,28 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
 // answer lets phase 1 skip them.  Visited marks are stamps of a fresh epoch in the searcher's own table, the queue is
 // a ring in its heap spill area.  Returns 1 reachable, 2 not, 0 unknown (ring overflow).
 __device__ int reach_strict_wave(const Dev& d, AScratch& S, int start, int goal) {
-  const int W = d.W, H = d.H, lane = lane_id();
+  const int lane = lane_id();
   start = uni(start); goal = uni(goal);
   const uint32_t stamp = (uint32_t)uni((int)next_epoch(d, S)) << T_STAMP_SHIFT;
-  int32_t* ring = reinterpret_cast<int32_t*>(S.gq);
-  TEnt* const tab = S.tab;
+  const int W = uni(d.W), H = uni(d.H), W8 = uni(d.W8);
+  const u64 w_magic = uni64(d.w_magic);
+  const gi32p ring = (gi32p)(uintptr_t)uni64((u64)(uintptr_t)S.gq);
+  TS_GLOBAL uint32_t* const tabw = (TS_GLOBAL uint32_t*)(uintptr_t)uni64((u64)(uintptr_t)S.tab);   // record t: dist at 2t, meta at 2t + 1
+  const TS_GLOBAL uint16_t* amap = (const TS_GLOBAL uint16_t*)(uintptr_t)uni64((u64)(uintptr_t)d.amap);
   const unsigned qcap = (unsigned)uni(S.heap_cap - LDS_HEAP) * 2u;
   if (qcap < 256u) return 0;
+  auto xy_of = [&](int cell, int& x, int& y) {
+    if (w_magic) { y = (int)(((u64)(unsigned)cell * w_magic) >> 40); x = cell - y * W; }
+    else { y = cell / W; x = cell - y * W; }
+  };
+  auto tile_ix = [&](int x, int y) -> uint32_t {
+    return ((((uint32_t)(y >> 3) * (uint32_t)W8 + (uint32_t)(x >> 3)) << 6) | (uint32_t)((y & 7) << 3) | (uint32_t)(x & 7));
+  };
   if (lane == 0) {
     int sx, sy;
-    cell_xy(d, start, sx, sy);
+    xy_of(start, sx, sy);
     ring[0] = start;
-    tab[tix(d, sx, sy)].meta = stamp;
+    tabw[2 * (size_t)tile_ix(sx, sy) + 1] = stamp;
   }
   __syncthreads();
   unsigned head = 0, tail = 1;
@@ -352,15 +459,17 @@ __device__ int reach_strict_wave(const Dev& d, AScratch& S, int start, int goal)
     const int c = idx < tail ? ring[idx % qcap] : -1;
     head = min(tail, head + 64u);
     int cx = 0, cy = 0;
-    if (c >= 0) cell_xy(d, c, cx, cy);
-    const uint32_t bits = c >= 0 ? (uint32_t)d.amap[tix(d, cx, cy)] & 15u : 0u;
+    if (c >= 0) xy_of(c, cx, cy);
+    const uint32_t bits = c >= 0 ? (uint32_t)amap[tile_ix(cx, cy)] & 15u : 0u;
     for (int dd = 0; dd < 4; dd++) {
       int n = -1;
       if (bits & (1u << dd)) {
         const int nx = cx + (dd == 1) - (dd == 3), ny = cy + (dd == 0) - (dd == 2);
         if (nx >= 0 && nx < W && ny >= 0 && ny < H) {
-          const uint32_t tn = tix(d, nx, ny);
-          if (((uint32_t)d.amap[tn] & 0x300u) == 0u && atomicExch(&tab[tn].meta, stamp) != stamp) n = ny * W + nx;
+          const uint32_t tn = tile_ix(nx, ny);
+          if (((uint32_t)amap[tn] & 0x300u) == 0u &&
+              __hip_atomic_exchange(&tabw[2 * (size_t)tn + 1], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp)
+            n = ny * W + nx;
         }
       }
       const unsigned long long m = __ballot(n >= 0);
@@ -896,8 +1005,13 @@ __global__ void __launch_bounds__(64) k_astar_single(Dev d, TsParams P, ASlots s
   if (blockIdx.x) return;
   AScratch S;
   scratch_bind(sl, 0, S);
+  const long long c0 = clock64(), w0 = wall_clock64();
   int len = astar_wave(d, P, S, start_idx, goal_idx, soft != 0, ignore_flow != 0, maximum_steps, S.A, S.cap);
   if (threadIdx.x) return;
+  {  // probe figures (profiles/astar_probe.py): shader cycles and 100 MHz wall ticks the search took
+    const long long dc = clock64() - c0, dw = wall_clock64() - w0;
+    d.cnt->dbg[0] = (int)(dc & 0xFFFFFFFF); d.cnt->dbg[1] = (int)(dc >> 32); d.cnt->dbg[2] = (int)(dw & 0xFFFFFFFF); d.cnt->dbg[3] = (int)(dw >> 32);
+  }
   sl.slot_epoch[0] = S.epoch;
   if (len >= 0) {
     atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);

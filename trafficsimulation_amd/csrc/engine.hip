@@ -1377,6 +1377,14 @@ int ts_counters(ts_handle e, TsCounters* out) {
   return TS_OK;
 }
 
+// profiling hook (not part of include/trafficsim.h): the eight debug words the last replanning / search kernel left
+int ts_debug_read(ts_handle e, int32_t* out8) {
+  if (!e || !out8) return TS_E_INVALID;
+  HIPOK(hipStreamSynchronize(e->stream));
+  HIPOK(hipMemcpy(out8, e->d.cnt->dbg, sizeof(int) * 8, hipMemcpyDeviceToHost));
+  return TS_OK;
+}
+
 int ts_set_device(int32_t device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return TS_E_DEVICE;
