@@ -50,7 +50,7 @@ def main():
             cyc = (dbg[0] & 0xFFFFFFFF) | (dbg[1] << 32)
             wall = ((dbg[2] & 0xFFFFFFFF) | (dbg[3] << 32)) * 10.0   # ns
             print(f"q{q} soft={int(soft)} md={abs(sx-gx)+abs(sy-gy)} len={len(path)} exp={ex} relax={c1.astar_relaxations - c0.astar_relaxations} "
-                  f"{dt*1e3:.2f} ms  {dt/max(ex,1)*1e9:.0f} ns/exp  kernel {wall/1e6:.2f} ms, {cyc/max(ex,1):.0f} cycles/exp, {cyc/max(wall,1):.2f} GHz")
+                  f"{dt*1e3:.2f} ms  {dt/max(ex,1)*1e9:.0f} ns/exp  kernel {wall/1e6:.2f} ms, {cyc/max(ex,1):.0f} cycles/exp, {cyc/max(wall,1):.2f} GHz, max heap {dbg[4]}")
             if ex > 2000:
                 tot_exp += ex
                 tot_t += dt

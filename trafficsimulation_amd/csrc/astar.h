@@ -41,7 +41,8 @@ constexpr int A_INF = 0x3F3F3F3F;
 constexpr int MAXB = 64;  // longest contraflow bypass (VEHICLE_MAX_CONTRAFLOW_*_STEPS <= 64)
 enum { DV_DONE = 0, DV_DEFER = 1, DV_OVERFLOW = 2, DV_POOL_FULL = 3 };
 
-constexpr int LDS_HEAP = 4096;            // heap slots (and dir bytes) a searcher keeps in LDS: 36 KB, four searchers per CU
+constexpr int LDS_HEAP = 2048;            // heap slots (and dir bytes) a searcher keeps in LDS: 18 KB, eight searchers per CU
+                                          // (two per SIMD; the deepest heap seen on 1024^2 / 2048^2 runs is ~1500 entries)
 struct __attribute__((aligned(8))) HQ { int32_t f, i; };             // heap entry: f_arr, i_arr (g_arr / s_arr: see above)
 struct __attribute__((aligned(8))) TEnt { int32_t dist; uint32_t meta; };   // meta = stamp << 14 | steps << 2 | came-from direction
 constexpr uint32_t T_STAMP_SHIFT = 14, T_STEPS_MASK = 0xFFF, T_STAMP_MAX = (1u << 18) - 1;
@@ -173,6 +174,8 @@ struct ACtx {
   bool soft, ignore_flow, limited, turn_on, rt_on, dens_on;
   double turn_pen, contra_pen, veh_pen, stop_pen, dyn_scale, rt1, rt2, rt3;
   long long n_exp, n_relax;
+  int max_heap;
+  long long prof[8], pt;
   __device__ __forceinline__ void xy_of(int cell, int& x, int& y) const {
     if (w_magic) { y = (int)(((u64)(unsigned)cell * w_magic) >> 40); x = cell - y * W; }
     else { y = cell / W; x = cell - y * W; }
@@ -181,6 +184,11 @@ struct ACtx {
     return ((((uint32_t)(y >> 3) * (uint32_t)W8 + (uint32_t)(x >> 3)) << 6) | (uint32_t)((y & 7) << 3) | (uint32_t)(x & 7));
   }
 };
+#ifdef TS_KPROF
+#define KP(k) do { const long long _t = clock64(); C.prof[k] += _t - C.pt; C.pt = _t; } while (0)
+#else
+#define KP(k) do { } while (0)
+#endif
 enum { AL_EMPTY = -2, AL_OVERFLOW = -1, AL_SWITCH = -3 };   // astar_loop results besides a path length >= 0
 
 // ---------------------------------------------------------------------------------------------
@@ -214,19 +222,24 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
   // window geometry of this lane (lanes 2..63 = the 62 entries of five levels below a hole that sits on "lane 1")
   const int wlvl = 31 - __builtin_clz((unsigned)max(lane, 1));   // 1 for lanes 2-3, ... 5 for 32-63
   const int woff = lane - (1 << wlvl);
-  const bool wleft = (lane & 1) == 0;
+  const bool wlane = lane >= 2;
+  const int wadj = (lane & 1) == 0 ? 1 : 0;                       // left children (even lanes) win ties against their sibling
+  unsigned long long wanc = 0;                                     // this lane's ancestors-or-self inside the window
+  for (int j = 0; j < wlvl; j++) wanc |= 1ull << (lane >> j);
   const int dd_l = lane & 3;
   const int dx_l = lane < 4 ? (dd_l == 1) - (dd_l == 3) : 0, dy_l = lane < 4 ? (dd_l == 0) - (dd_l == 2) : 0;
   const unsigned below_l = (1u << lane) - 1u;                      // (lanes 0-3 use it)
   while (heap_size > 0) {
     if (!SPILL && heap_size > LDS_HEAP - 4) return AL_SWITCH;        // this turn's pushes might not fit LDS
     if (SPILL && heap_size < LDS_HEAP / 2) return AL_SWITCH;
+    KP(7);
     const u64 top = g_lq[0];
     const int prev_dir = uni((int)g_ld[0]);
     const u64 x = uni64(hq_get<SPILL>(gq, heap_size - 1));            // the last entry: it takes the root's place
     const int xd = uni(hd_get<SPILL>(gd, heap_size - 1));
     const int f_top = uni(hq_f(top)), cur = uni(hq_i(top));
     heap_size--;
+    KP(0);
     int cx, cy;
     C.xy_of(cur, cx, cy);
     const int nx_l = cx + dx_l, ny_l = cy + dy_l;
@@ -236,6 +249,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     const uint32_t a_l = C.amap[t_l];
     const u64 e_l = tab[t_l];
     const float dens_l = C.density[nidx_l];      // (read whether or not the search is soft: no branch around a load)
+    KP(1);
     if (heap_size > 0) {
       const int xf = hq_f(x);
       wave_mem_sync();                     // every lane has read slot 0 before it is overwritten
@@ -243,32 +257,31 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
       int idx = 0;                         // the hole; x keeps sinking
       for (;;) {
         const int abs_l = ((idx + 1) << wlvl) + woff - 1;
-        const bool valid = lane >= 2 && abs_l < heap_size;
+        const bool valid = wlane & (abs_l < heap_size);
         const u64 mine = hq_get<SPILL>(gq, valid ? abs_l : 0);
         const int mf = valid ? hq_f(mine) : 0x7FFFFFFF;
         const int sf = __builtin_amdgcn_mov_dpp(mf, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: the sibling's key
         // smallest of (x, left, right) with ties going to x, then left (heap_sift_down, astar_numba.py:67-85):
-        // "my entry moves up if my parent is the hole" - at most one of two siblings
-        const bool win = mf < xf && (wleft ? mf <= sf : mf < sf);
-        const unsigned long long wmask = __ballot(win);
-        // follow the winners from the hole (virtual lane 1) down the five levels: scalar, branch-free
-        int L = 1, k = 0;
-        bool alive = true;
-#pragma unroll
-        for (int lv = 0; lv < 5; lv++) {
-          const unsigned m = (unsigned)(wmask >> (2 * L)) & 3u;      // the two children of L: at most one bit set
-          alive = alive && m != 0u;
-          L = alive ? 2 * L + (int)(m >> 1) : L;
-          k += alive ? 1 : 0;
-        }
-        // lanes on the path (levels 1..k, ancestors-or-self of L) hand their entry to the parent's slot
-        if (wlvl >= 1 && wlvl <= k && (L >> (k - wlvl)) == lane) hq_put<SPILL>(gq, (abs_l - 1) >> 1, mine);
-        const int abs_end = ((idx + 1) << k) + (L - (1 << k)) - 1;
-        if (k < 5) { if (lane == 0) hq_put<SPILL>(gq, abs_end, x); break; }
+        // "my entry moves up if my parent is the hole" - at most one of two siblings.  Left: mine <= sibling's, right:
+        // mine < sibling's; keys are >= 0, so mine <= s is (mine - 1) < s.
+        const unsigned long long wmask = __ballot((mf < xf) & ((mf - wadj) < sf));
+        // A lane's entry is on the sift path iff it and all its ancestors inside the window are winners: one mask
+        // test per lane (wanc = the lane's ancestors-or-self).  Exactly one lane per level can pass, so a second
+        // ballot yields both the number of levels the hole sinks (k) and where it ends up (L).
+        const bool onp = wlane & ((wmask & wanc) == wanc);
+        const unsigned long long pmask = __ballot(onp);
+        const int k = __builtin_popcountll(pmask);
+        const int L = 63 - __builtin_clzll(pmask | 2ull);             // deepest lane on the path; the hole itself (1) if none
+        if (onp) hq_put<SPILL>(gq, (abs_l - 1) >> 1, mine);          // the entries on the path move up one level
+        const int abs_end = uni(((idx + 1) << k) + (L - (1 << k)) - 1);
+        const bool done = k < 5;
+        if (done & (lane == 0)) hq_put<SPILL>(gq, abs_end, x);
+        if (done) break;
         idx = abs_end;                     // five levels down and still sinking: next window
       }
     }
     wave_mem_sync();
+    KP(2);
     if (cur == C.goal_idx) {
       // walk came_from back to the start, filling the output from its far end, then slide it to the front
       const gi32p outg = C.outg;
@@ -300,55 +313,46 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
       const int dist_c = (m_c >> T_STAMP_SHIFT) == epoch ? (int)(uint32_t)e_c : A_INF;
       if (g > dist_c) continue;
     }
+    KP(3);
     C.n_exp++;
     const int steps = C.limited ? (int)((m_c >> 2) & T_STEPS_MASK) : 0;
     const uint32_t bits = (uint32_t)rl((int)a_l, 4) & 15u;
     // ---- lane dd < 4 evaluates neighbour dd from what was fetched before the sift-down -------------------------
-    bool ok_l = lane < 4 && inb_l && steps + 1 <= C.maximum_steps;
-    double ng_l = g + 1;
+    double ng_l = (double)(g + 1);
+    bool ok_l;
     {
       const uint32_t m_l = (uint32_t)(e_l >> 32);
       const int dist_l = (m_l >> T_STAMP_SHIFT) == epoch ? (int)(uint32_t)e_l : A_INF;
-      const int n_occ = (int)((a_l >> 8) & 1u), n_stop = (int)((a_l >> 9) & 1u);
-      const uint8_t n_stat = (uint8_t)(a_l & 0xFF);
-      if (C.turn_on && prev_dir != -1 && dd_l != prev_dir) ng_l += C.turn_pen;
-      if ((bits & (1u << dd_l)) == 0) {
-        if (C.ignore_flow && st_is_road(n_stat) == 1) ng_l += C.contra_pen;
-        else ok_l = false;
-      }
-      if (n_occ == 1) {
-        if (C.dens_on) {
-          double local_density = (double)dens_l;
-          ng_l += (double)(long long)(C.veh_pen * (1.0 + C.dyn_scale * local_density));
-        } else if (C.soft) ng_l += C.veh_pen;
-        else ok_l = false;
-      }
-      if (n_stop == 1) {
-        if (C.soft) ng_l += C.stop_pen;
-        else ok_l = false;
-      }
-      if (C.rt_on && st_is_road(n_stat) == 1) {
-        int rt = st_road_type(n_stat);
-        if (rt == 1) ng_l += C.rt1;
-        else if (rt == 2) ng_l += C.rt2;
-        else if (rt == 3) ng_l += C.rt3;
-      }
-      if (!(ng_l < (double)dist_l)) ok_l = false;
+      const bool n_occ = ((a_l >> 8) & 1u) != 0u, n_stop = ((a_l >> 9) & 1u) != 0u, n_road = ((a_l >> 4) & 1u) != 0u;
+      const uint32_t rt = (a_l >> 6) & 3u;
+      const bool flow = ((bits >> dd_l) & 1u) != 0u;
+      // (selects, not branches: a killed neighbour's cost is simply not used)
+      ng_l += (C.turn_on & (prev_dir != -1) & (dd_l != prev_dir)) ? C.turn_pen : 0.0;
+      ng_l += flow ? 0.0 : C.contra_pen;
+      const double occ_pen = C.dens_on ? __builtin_trunc(C.veh_pen * (1.0 + C.dyn_scale * (double)dens_l)) : C.veh_pen;
+      ng_l += n_occ ? occ_pen : 0.0;
+      ng_l += n_stop ? C.stop_pen : 0.0;
+      ng_l += (C.rt_on & n_road) ? (rt == 1u ? C.rt1 : rt == 2u ? C.rt2 : rt == 3u ? C.rt3 : 0.0) : 0.0;
+      ok_l = (lane < 4) & inb_l & (steps + 1 <= C.maximum_steps) & (flow | (C.ignore_flow & n_road)) & (C.soft | !(n_occ | n_stop)) &
+             (ng_l < (double)dist_l);
     }
     // ---- commit.  The four neighbours are distinct cells, so no relaxation changes another one's test: the table
     // records and the dir bytes of all of them go out with one masked store each; only the heap pushes are made one
     // after the other, in the reference's order N, E, S, W.
     unsigned relax = (unsigned)(__ballot(ok_l) & 15ull);
+    KP(4);
     if (relax == 0u) continue;
     const int n_new = __builtin_popcount(relax);
     C.n_relax += n_new;
     if (heap_size + n_new > C.heap_cap) return AL_OVERFLOW;
+    C.max_heap = max(C.max_heap, heap_size + n_new);
     const int ngi_l = (int)ng_l;
     const u64 ent_l = hq_pack((int)(ng_l + (double)(abs(nx_l - gx) + abs(ny_l - gy))), nidx_l);
     if (ok_l) {
       tab[t_l] = (u64)(uint32_t)ngi_l | ((u64)(stamp | (C.limited ? (uint32_t)(steps + 1) << 2 : 0u) | (uint32_t)dd_l) << 32);
       hd_put<SPILL>(gd, heap_size + __builtin_popcount(relax & below_l), dd_l);
     }
+    KP(5);
     while (relax) {
       const int dd = __builtin_ctz(relax);
       relax &= relax - 1;
@@ -358,15 +362,16 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
       // ancestors of slot i: a_k = ((i + 1) >> k) - 1, k = 1 .. depth; lane k - 1 fetches a_k
       const int depth = 31 - __builtin_clz((unsigned)(i + 1));
       const bool has = lane < depth;                                  // depth <= 31: lanes beyond it fetch nothing
-      const int a_mine = has ? ((i + 1) >> (lane + 1)) - 1 : 0;      // (an unguarded shift by lane + 1 >= 32 is undefined)
+      const int a_mine = (int)(((unsigned)(i + 1) >> ((lane + 1) & 31)) - 1u) & (has ? -1 : 0);
       const u64 anc = hq_get<SPILL>(gq, a_mine);
-      const unsigned long long rises = __ballot(has && nf < hq_f(anc));
-      const int r = rises == ~0ull ? 64 : __builtin_ctzll(~rises);      // leading ancestors the entry passes
-      if (lane < r) hq_put<SPILL>(gq, ((i + 1) >> lane) - 1, anc);      // ancestor k moves to where k - 1 was
+      const unsigned long long rises = __ballot(has & (nf < hq_f(anc)));
+      const int r = __builtin_ctzll(~rises);                          // leading ancestors the entry passes (lanes >= 31 never rise)
+      if (lane < r) hq_put<SPILL>(gq, (int)((unsigned)(i + 1) >> (lane & 31)) - 1, anc);   // ancestor k moves to where k - 1 was
       if (lane == 0) hq_put<SPILL>(gq, ((i + 1) >> r) - 1, nx64);
       heap_size++;
       wave_mem_sync();
     }
+    KP(6);
   }
   return AL_EMPTY;
 }
@@ -397,7 +402,9 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   C.turn_pen = P.turn_penalty; C.contra_pen = P.contraflow_penalty; C.veh_pen = P.obstacle_penalty_vehicle;
   C.stop_pen = P.obstacle_penalty_stop; C.dyn_scale = P.dynamic_penalty_scale; C.rt1 = P.road_type_penalty_r1;
   C.rt2 = P.road_type_penalty_r2; C.rt3 = P.road_type_penalty_r3;
-  C.n_exp = 0; C.n_relax = 0;
+  C.n_exp = 0; C.n_relax = 0; C.max_heap = 0;
+  for (int k = 0; k < 8; k++) C.prof[k] = 0;
+  C.pt = clock64();
   // the chain of relaxations behind a heap entry never revisits a cell (dist strictly falls), so it is shorter than
   // N: a limit of N or more never binds and the steps need not be carried
   C.limited = C.maximum_steps < C.N;
@@ -419,6 +426,13 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
     if (r != AL_SWITCH) break;
   }
   S.expansions += C.n_exp; S.relaxations += C.n_relax;
+  if (C.lane == 0) {   // profiling aid: deepest heap / longest search any searcher has seen (ts_debug_read words 4, 5)
+    atomicMax(&d.cnt->dbg[4], C.max_heap);
+    atomicMax(&d.cnt->dbg[5], (int)min(C.n_exp, (long long)0x7FFFFFFF));
+#ifdef TS_KPROF
+    for (int k = 0; k < 8; k++) d.cnt->prof[k] = C.prof[k];
+#endif
+  }
   return r == AL_EMPTY ? 0 : r;
 }
 

@@ -43,6 +43,7 @@ struct DevCnt {
   unsigned int rng_event;   // first (vehicle index * 2 + is_collision) whose draw fired this pass, 0xFFFFFFFF = none
   unsigned int rng_tot[2];  // pass 1 totals: fixed words, number of speed rolls
   int pad_;
+  long long prof[8];   // TS_KPROF builds: cycles per segment of the last search's loop
   int dbg[8];      // debugging aid: first watchdog that fired inside a replanning kernel (code, vehicle index, values)
 };
 

@@ -79,7 +79,7 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     if (getenv("TS_DEBUG_REPLAN")) {
       int dbg[8];
       HIPOK(hipMemcpy(dbg, d.cnt->dbg, sizeof(dbg), hipMemcpyDeviceToHost));
-      if (dbg[0]) fprintf(stderr, "[replan] watchdog %d: %d %d %d %d %d %d %d\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
+      fprintf(stderr, "[replan] deepest heap so far %d, longest search so far %d expansions\n", dbg[4], dbg[5]);
     }
     if (e->hint[3] == TS_E_CAPACITY) return fail(e, TS_E_CAPACITY, "an A* search exceeded its heap or path buffers");
     const int retry = e->hint[8 + 4];
@@ -1382,6 +1382,11 @@ int ts_debug_read(ts_handle e, int32_t* out8) {
   if (!e || !out8) return TS_E_INVALID;
   HIPOK(hipStreamSynchronize(e->stream));
   HIPOK(hipMemcpy(out8, e->d.cnt->dbg, sizeof(int) * 8, hipMemcpyDeviceToHost));
+  if (getenv("TS_KPROF")) {
+    long long pr[8];
+    HIPOK(hipMemcpy(pr, e->d.cnt->prof, sizeof(pr), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[kprof] top %lld | issue loads %lld | sift-down %lld | goal+stale %lld | evaluate %lld | commit stores %lld | pushes %lld | loop %lld\n", pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
+  }
   return TS_OK;
 }
 
