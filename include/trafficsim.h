@@ -371,6 +371,19 @@ int ts_astar(ts_handle h, int32_t sx, int32_t sy, int32_t gx, int32_t gy, int32_
  * rank r of a multi-GPU launch calls ts_set_device(LOCAL_RANK)). */
 int ts_set_device(int32_t device);
 
+/* Multi-GPU, replicated state / sharded replans (the all-gather variant): every rank of a
+ * one-process-per-GPU job holds the whole world and is stepped with the same calls and seeds; the replanning searches
+ * of a tick - 99 % of a default-policy tick - are split by decide-order index (index % world == rank), and the ranks
+ * trade what those step_decides changed (paths, timers, flags, counters) through `exchange` once per tick, so that
+ * every rank ends the tick with the state a single GPU would have: bit for bit (tests/test_gpu_dist.py).  The
+ * reference has no distributed code; the contract is this build's.
+ * `exchange(user, send, send_bytes, &recv, &sizes, &stride)` is an all-gather of variable-size byte buffers in host
+ * memory: on return recv points at world slots of `stride` bytes (slot r = rank r's buffer, sizes[r] bytes of it
+ * valid), owned by the callee until the next call.  It returns 0 or a negative error.  Over torch.distributed it
+ * is an all_gather on RCCL (backend "nccl") or gloo: trafficsimulation_amd/dist.py.  world == 1 switches it off. */
+typedef int (*ts_exchange_fn)(void* user, const void* send, int64_t send_bytes, void** recv, int64_t** sizes, int64_t* stride);
+int ts_set_replan_sharding(ts_handle h, int32_t rank, int32_t world, ts_exchange_fn exchange, void* user);
+
 /* Per-kernel timing with HIP events recorded on the engine's own stream (bench.py's roofline leg).
  * ts_profile_enable(h, 1) starts collecting; ts_profile_get returns, for kernel class `kernel_id`
  * (0 <= id < ts_profile_count()), the summed device time in ms, the number of launches and the

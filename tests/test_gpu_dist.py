@@ -1,0 +1,65 @@
+"""Multi-GPU mode "replicated state / sharded replans" on the GPU: two ranks (two processes on this box's one GPU,
+gloo underneath - RCCL refuses two ranks on one device) each replay a reference trace with the full replanning policy;
+every rank plans half of each tick's searches, the results are exchanged, and BOTH ranks must match the reference's
+recorded state at every tick - i.e. the N-rank result equals the 1-GPU result bit for bit."""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from trafficsimulation_amd import dist as tdist
+from trafficsimulation_amd import _capi as capi
+from trafficsimulation_amd._lib import new_engine
+from trafficsimulation_amd.world import load_trace
+from tests.trace_util import setup_from_trace, check_initial, replay_and_compare, trace_path
+rank, local, world = tdist.env_rank()
+d = tdist.init("gloo", rank, world)
+res = {}
+for name in %(traces)r:
+    tr = load_trace(trace_path(name))
+    api = new_engine()
+    setup_from_trace(api, tr, explicit_paths=False)
+    check_initial(api, tr)
+    sr = tdist.ShardedReplans().attach(api)
+    n = replay_and_compare(api, tr)          # raises on the first tick that differs from the reference
+    c = api.counters()
+    res[name] = dict(ticks=n, astar_calls=int(c.astar_calls), want_calls=int(tr["astar_calls_spawn"]) + int(tr["astar_per_tick"].sum()),
+                     exchanges=sr.calls, bytes=sr.bytes_sent, fp=list(api.rng_fingerprint(capi.RNG_GLOBAL)))
+    api.close()
+print(json.dumps(dict(rank=rank, res=res)), flush=True)
+d.destroy_process_group()
+'''
+
+
+def test_two_ranks_sharded_replans_match_the_reference():
+    traces = ["full_64_s1", "full_96_s8", "faults_64_s9", "carve_96_s10"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(WORKER % dict(root=ROOT, traces=traces))
+        path = f.name
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", path]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    os.unlink(path)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    rows = [json.loads(line) for line in out.stdout.splitlines() if line.startswith('{"rank"')]
+    assert sorted(r["rank"] for r in rows) == [0, 1]
+    r0, r1 = sorted(rows, key=lambda r: r["rank"])
+    for name in traces:
+        a, b = r0["res"][name], r1["res"][name]
+        assert a["ticks"] == b["ticks"] > 0
+        assert a["astar_calls"] == b["astar_calls"] == a["want_calls"]     # the searches of both ranks add up to the reference's
+        assert a["fp"] == b["fp"]
+        assert a["exchanges"] == b["exchanges"] > 0 and a["bytes"] > 0 and b["bytes"] > 0   # both ranks planned something

@@ -178,6 +178,11 @@ UNSUPPORTED_DEFAULTS = {
 }
 
 
+# ts_exchange_fn (include/trafficsim.h): all-gather of variable-size host byte buffers
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                          C.POINTER(C.c_int64))
+
+
 class EngineError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"trafficsim error {code}: {msg}")
@@ -235,6 +240,7 @@ class CApi:
         f("astar").argtypes = [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p, C.c_int32]
         f("debug_set_occupancy").argtypes = [C.c_void_p, C.c_void_p]
         f("set_device").argtypes = [C.c_int32]
+        f("set_replan_sharding").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         f("profile_enable").argtypes = [C.c_void_p, C.c_int32]
         f("profile_name").restype = C.c_char_p
         f("profile_name").argtypes = [C.c_int32]
@@ -430,6 +436,12 @@ class CApi:
             self._chk(self._f("profile_get")(self.h, k, C.byref(ms), C.byref(n), C.byref(it)))
             out[self._f("profile_name")(k).decode()] = (ms.value, n.value, it.value)
         return out
+
+    def set_replan_sharding(self, rank: int, world: int, callback):
+        """ts_set_replan_sharding: `callback` is an EXCHANGE_FN instance (kept alive here) or None for world == 1."""
+        self._exchange_cb = callback
+        ptr = C.cast(callback, C.c_void_p) if callback is not None else None
+        self._chk(self._f("set_replan_sharding")(self.h, int(rank), int(world), ptr, None))
 
     def debug_set_occupancy(self, arr):
         """Test hook: overwrite occupancy_map without placing vehicles (A*/density KATs)."""

@@ -894,17 +894,21 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
     for (int k = 0; k < 4; k++) if (v.ax_staged[k]) words += (v.ax_len[k] + 15) / 16;
     uint32_t off = 0;
     if (words > 0 && !pool_alloc<WAVE>(d, words, off)) return DV_POOL_FULL;
+    uint8_t chg = 0;
     if (path_changed) {
       encode_cells(d, off, v.pos, S->P, v.plen);
       d.path_off[vid] = off; d.path_len[vid] = v.plen; d.path_cur[vid] = 0;
       off += (v.plen + 15) / 16;
+      chg |= 1;
     }
     for (int k = 0; k < 4; k++) {
       if (!v.ax_staged[k]) continue;
       encode_cells(d, off, v.pos, ax_buf(*S, k), v.ax_len[k]);
       d.ax_start[k][vid] = v.pos; d.ax_off[k][vid] = off; d.ax_len[k][vid] = v.ax_len[k];
       off += (v.ax_len[k] + 15) / 16;
+      chg |= (uint8_t)(2 << k);
     }
+    if (chg) d.chg[vid] = chg;
   }
   if (reached_body) {
     if (ax_none_set[0] && !v.ax_staged[0]) d.ax_len[0][vid] = -1;
@@ -1011,6 +1015,77 @@ __global__ void __launch_bounds__(64) k_replan(Dev d, TsParams P, ASlots sl, RLi
   q.retry_list = retry_list; q.owned_list = owned_list; q.rank = rank; q.world = world;
   while (uni(replan_turn(d, P, &S, q))) {}
   if (threadIdx.x == 0) sl.slot_epoch[blockIdx.x] = S.epoch;
+}
+
+// ---- replicated-state multi-GPU mode (ts_set_replan_sharding) ------------------------------------------------------
+// What step_decide changed about a vehicle this rank planned, for the ranks that did not: one fixed record plus the
+// 2-bit direction words of whatever paths the replan rewrote.
+struct ReplanRec {
+  int32_t i, vid, flags, base, cur, max_steps, cooldown, over_dur, det_dur, stranded_left, hint;
+  int32_t path_len, path_woff;          // path_woff < 0: the path was left as it is
+  int32_t ax_len[4], ax_start[4], ax_woff[4];
+  int32_t pad_[3];
+};
+static_assert(sizeof(ReplanRec) == 112, "ReplanRec is exchanged as 28 ints");
+__global__ void k_replan_export(Dev d, const int32_t* owned, int n, ReplanRec* recs, uint32_t* words, unsigned long long* words_n) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int i = owned[t];
+  const int vid = d.active[i];
+  ReplanRec r;
+  r.i = i; r.vid = vid;
+  r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+  if (vid < 0) { recs[t] = r; return; }
+  r.flags = d.flags[vid]; r.base = d.base_speed[vid]; r.cur = d.cur_speed[vid]; r.max_steps = d.max_steps[vid];
+  r.cooldown = d.cooldown[vid]; r.over_dur = d.over_dur[vid]; r.det_dur = d.det_dur[vid];
+  r.stranded_left = d.stranded_left[vid]; r.hint = d.tier_hint[vid];
+  const uint8_t chg = d.chg[vid];
+  d.chg[vid] = 0;
+  r.path_len = d.path_len[vid]; r.path_woff = -1;
+  if (chg & 1) {
+    const int nw = (r.path_len + 15) >> 4;
+    const unsigned long long w = atomicAdd(words_n, (unsigned long long)nw);
+    const uint32_t src = d.path_off[vid];
+    for (int q = 0; q < nw; q++) words[w + q] = d.pool[src + q];
+    r.path_woff = (int32_t)w;
+  }
+  for (int k = 0; k < 4; k++) {
+    r.ax_len[k] = d.ax_len[k][vid]; r.ax_start[k] = d.ax_start[k][vid]; r.ax_woff[k] = -1;
+    if ((chg >> (1 + k)) & 1) {
+      const int nw = (r.ax_len[k] + 15) >> 4;
+      const unsigned long long w = atomicAdd(words_n, (unsigned long long)nw);
+      const uint32_t src = d.ax_off[k][vid];
+      for (int q = 0; q < nw; q++) words[w + q] = d.pool[src + q];
+      r.ax_woff[k] = (int32_t)w;
+    }
+  }
+  recs[t] = r;
+}
+// the same in the other direction: records of vehicles another rank planned (pool capacity ensured by the host)
+__global__ void k_replan_import(Dev d, const ReplanRec* recs, int n, const uint32_t* words) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const ReplanRec r = recs[t];
+  const int vid = r.vid;
+  if (vid < 0) return;
+  d.flags[vid] = (uint16_t)r.flags; d.base_speed[vid] = (int8_t)r.base; d.cur_speed[vid] = (int8_t)r.cur;
+  d.max_steps[vid] = (int8_t)r.max_steps; d.cooldown[vid] = r.cooldown; d.over_dur[vid] = r.over_dur; d.det_dur[vid] = r.det_dur;
+  d.stranded_left[vid] = r.stranded_left; d.tier_hint[vid] = (uint8_t)r.hint;
+  if (r.path_woff >= 0) {
+    const int nw = (r.path_len + 15) >> 4;
+    const uint32_t o = (uint32_t)atomicAdd((unsigned long long*)&d.cnt->pool_used, (unsigned long long)nw);
+    for (int q = 0; q < nw; q++) d.pool[o + q] = words[r.path_woff + q];
+    d.path_off[vid] = o; d.path_len[vid] = r.path_len; d.path_cur[vid] = 0;
+  }
+  for (int k = 0; k < 4; k++) {
+    d.ax_len[k][vid] = r.ax_len[k];
+    if (r.ax_woff[k] >= 0) {
+      const int nw = (r.ax_len[k] + 15) >> 4;
+      const uint32_t o = (uint32_t)atomicAdd((unsigned long long*)&d.cnt->pool_used, (unsigned long long)nw);
+      for (int q = 0; q < nw; q++) d.pool[o + q] = words[r.ax_woff[k] + q];
+      d.ax_start[k][vid] = r.ax_start[k]; d.ax_off[k][vid] = o;
+    }
+  }
 }
 
 // one search on the current maps (the `astar(...)` operator seam, ts_astar) - searcher slot 0

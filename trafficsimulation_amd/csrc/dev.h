@@ -90,6 +90,8 @@ struct Dev {
   uint32_t* ax_off[4];
   int32_t* ax_len[4];
   uint8_t* tier_hint;  // per vehicle: cost class (0..3) of its last replan, orders the replanning work queue
+  uint8_t* chg;        // per vehicle: what its replan of this tick rewrote (bit 0 path, bits 1-4 aux paths) - read and cleared by
+                       // k_replan_export in the multi-GPU mode
   // what a search reads about a cell, as of the last tick start (or the last ensure_amap): static byte | occupied << 8 |
   // red << 9, in tiled order - one 128-byte line per 8 x 8 tile
   uint16_t* amap;

@@ -99,6 +99,116 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   return TS_OK;
 }
 
+// Replicated-state multi-GPU mode: after this rank's share of the replans, trade results with the other ranks.
+// `before` = the device counters as they were when the replanning phase began.
+struct XHeader { int64_t n_recs, n_words, n_arr, error; int64_t delta[16]; double ddelta[2]; };
+int exchange_replans(E* e, const DevCnt& before) {
+  Dev& d = e->d;
+  hipStream_t st = e->stream;
+  const double t0 = now_ms();
+  const int n_owned = e->hint[8 + 6];
+  if ((size_t)std::max(n_owned, 1) > e->cap_recs) {
+    const size_t nc = (size_t)n_owned * 2 + 1024;
+    int rc = regrow(e, &e->d_recs, 0, nc); if (rc) return rc;
+    e->cap_recs = nc;
+  }
+  if (!e->d_xwords_n) HIPOK(dalloc(e, &e->d_xwords_n, 1));
+  // the words this rank's replans wrote are the pool's growth since the phase began (an upper bound for the export)
+  HIPOK(hipMemcpyAsync(e->hcnt, d.cnt, sizeof(DevCnt), hipMemcpyDeviceToHost, st));
+  HIPOK(hipStreamSynchronize(st));
+  const DevCnt after = *e->hcnt;
+  const size_t grown = (size_t)(after.pool_used >= before.pool_used ? after.pool_used - before.pool_used : after.pool_used) + 16;
+  if (grown > e->cap_xwords) {
+    const size_t nc = grown * 2 + 4096;
+    int rc = regrow(e, &e->d_xwords, 0, nc); if (rc) return rc;
+    e->cap_xwords = nc;
+  }
+  HIPOK(hipMemsetAsync(e->d_xwords_n, 0, sizeof(unsigned long long), st));
+  if (n_owned > 0)
+    hipLaunchKernelGGL(k_replan_export, dim3(nblk(n_owned)), dim3(BLK), 0, st, d, e->owned_list, n_owned, e->d_recs, e->d_xwords, e->d_xwords_n);
+  unsigned long long n_words = 0;
+  HIPOK(hipMemcpyAsync(&n_words, e->d_xwords_n, sizeof(n_words), hipMemcpyDeviceToHost, st));
+  HIPOK(hipStreamSynchronize(st));
+  if (n_words > e->cap_xwords) return fail(e, TS_E_DEVICE, "replan export overran its word buffer (internal error)");
+  const int n_arr = after.arr_n - before.arr_n;
+  XHeader hd;
+  memset(&hd, 0, sizeof(hd));
+  hd.n_recs = n_owned; hd.n_words = (int64_t)n_words; hd.n_arr = n_arr; hd.error = after.error;
+  const long long dl[] = {after.stuck - before.stuck, after.collisions - before.collisions, after.malfunctions - before.malfunctions,
+                          after.overtaking - before.overtaking, after.in_stuck_detour - before.in_stuck_detour, after.parked - before.parked,
+                          after.completed_internal - before.completed_internal, after.completed_through - before.completed_through,
+                          after.dist_internal - before.dist_internal, after.dist_through - before.dist_through,
+                          after.astar_calls - before.astar_calls, after.astar_exp - before.astar_exp, after.astar_relax - before.astar_relax};
+  for (size_t q = 0; q < sizeof(dl) / sizeof(dl[0]); q++) hd.delta[q] = dl[q];
+  hd.ddelta[0] = after.dur_internal - before.dur_internal; hd.ddelta[1] = after.dur_through - before.dur_through;
+  const size_t bytes = sizeof(XHeader) + (size_t)n_owned * sizeof(ReplanRec) + (size_t)n_words * 4 + (size_t)std::max(n_arr, 0) * 12;
+  e->send_buf.resize(bytes);
+  uint8_t* p = e->send_buf.data();
+  memcpy(p, &hd, sizeof(hd)); p += sizeof(hd);
+  if (n_owned > 0) HIPOK(hipMemcpyAsync(p, e->d_recs, (size_t)n_owned * sizeof(ReplanRec), hipMemcpyDeviceToHost, st));
+  p += (size_t)n_owned * sizeof(ReplanRec);
+  if (n_words > 0) HIPOK(hipMemcpyAsync(p, e->d_xwords, (size_t)n_words * 4, hipMemcpyDeviceToHost, st));
+  p += (size_t)n_words * 4;
+  if (n_arr > 0) HIPOK(hipMemcpyAsync(p, d.arr + 3 * (size_t)before.arr_n, (size_t)n_arr * 12, hipMemcpyDeviceToHost, st));
+  HIPOK(hipStreamSynchronize(st));
+  void* recv = nullptr;
+  int64_t* sizes = nullptr;
+  int64_t stride = 0;
+  const int xrc = e->dist_fn(e->dist_user, e->send_buf.data(), (int64_t)bytes, &recv, &sizes, &stride);
+  if (xrc != 0 || !recv || !sizes) return fail(e, TS_E_DEVICE, "the replan exchange callback failed");
+  // apply the other ranks' results; counters through the host copy
+  DevCnt merged = after;
+  long long in_words = 0, in_arr = 0;
+  for (int r = 0; r < e->dist_world; r++) {
+    if (r == e->dist_rank) continue;
+    const uint8_t* q = (const uint8_t*)recv + (size_t)r * (size_t)stride;
+    if ((size_t)sizes[r] < sizeof(XHeader)) return fail(e, TS_E_DEVICE, "short replan exchange buffer");
+    XHeader h2;
+    memcpy(&h2, q, sizeof(h2));
+    in_words += h2.n_words; in_arr += h2.n_arr;
+    if ((size_t)sizes[r] != sizeof(XHeader) + (size_t)h2.n_recs * sizeof(ReplanRec) + (size_t)h2.n_words * 4 + (size_t)h2.n_arr * 12)
+      return fail(e, TS_E_DEVICE, "replan exchange buffer size mismatch");
+  }
+  if (in_words > 0) { int rc = pool_make_room(e, (size_t)in_words + 64); if (rc) return rc; }
+  if (in_arr > 0 && (long long)after.arr_n + in_arr > d.arr_cap) return fail(e, TS_E_CAPACITY, "more service records in one tick than the record buffer holds");
+  e->exchange_bytes += (long long)bytes;
+  int arr_at = after.arr_n;
+  for (int r = 0; r < e->dist_world; r++) {
+    if (r == e->dist_rank) continue;
+    const uint8_t* q = (const uint8_t*)recv + (size_t)r * (size_t)stride;
+    XHeader h2;
+    memcpy(&h2, q, sizeof(h2)); q += sizeof(h2);
+    merged.stuck += h2.delta[0]; merged.collisions += h2.delta[1]; merged.malfunctions += h2.delta[2]; merged.overtaking += h2.delta[3];
+    merged.in_stuck_detour += h2.delta[4]; merged.parked += h2.delta[5]; merged.completed_internal += h2.delta[6];
+    merged.completed_through += h2.delta[7]; merged.dist_internal += h2.delta[8]; merged.dist_through += h2.delta[9];
+    merged.astar_calls += h2.delta[10]; merged.astar_exp += h2.delta[11]; merged.astar_relax += h2.delta[12];
+    merged.dur_internal += h2.ddelta[0]; merged.dur_through += h2.ddelta[1];
+    if (h2.error && !merged.error) merged.error = (int)h2.error;
+    if (h2.n_recs > 0) {
+      if ((size_t)h2.n_recs > e->cap_recs) { const size_t nc = (size_t)h2.n_recs * 2; int rc = regrow(e, &e->d_recs, 0, nc); if (rc) return rc; e->cap_recs = nc; }
+      if ((size_t)h2.n_words + 16 > e->cap_xwords) { const size_t nc = (size_t)h2.n_words * 2 + 4096; int rc = regrow(e, &e->d_xwords, 0, nc); if (rc) return rc; e->cap_xwords = nc; }
+      HIPOK(hipMemcpyAsync(e->d_recs, q, (size_t)h2.n_recs * sizeof(ReplanRec), hipMemcpyHostToDevice, st));
+      if (h2.n_words > 0) HIPOK(hipMemcpyAsync(e->d_xwords, q + (size_t)h2.n_recs * sizeof(ReplanRec), (size_t)h2.n_words * 4, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_replan_import, dim3(nblk((long long)h2.n_recs)), dim3(BLK), 0, st, d, e->d_recs, (int)h2.n_recs, e->d_xwords);
+      HIPOK(hipStreamSynchronize(st));   // (the staging buffers are reused for the next rank)
+    }
+    if (h2.n_arr > 0) {
+      HIPOK(hipMemcpyAsync(d.arr + 3 * (size_t)arr_at, q + (size_t)h2.n_recs * sizeof(ReplanRec) + (size_t)h2.n_words * 4, (size_t)h2.n_arr * 12, hipMemcpyHostToDevice, st));
+      arr_at += (int)h2.n_arr;
+    }
+  }
+  // counters: the device copy moved on only in pool_used (imports); everything else is after + the others' deltas
+  unsigned long long pool_now = 0;
+  HIPOK(hipMemcpyAsync(&pool_now, &d.cnt->pool_used, sizeof(pool_now), hipMemcpyDeviceToHost, st));
+  HIPOK(hipStreamSynchronize(st));
+  merged.pool_used = pool_now; merged.arr_n = arr_at;
+  *e->hcnt = merged;
+  HIPOK(hipMemcpyAsync(d.cnt, e->hcnt, sizeof(DevCnt), hipMemcpyHostToDevice, st));
+  HIPOK(hipStreamSynchronize(st));
+  e->exchange_ms += now_ms() - t0;
+  return TS_OK;
+}
+
 // mirror the global stream's tempered words [uploaded, upto) into the device ring (copy stream + event)
 int words_upload(E* e, uint64_t upto) {
   MTPipe& r = e->rng_global;
@@ -348,7 +458,18 @@ int tick(E* e) {
         e->take_base = nb; e->take_n = nt;
       }
     }
-    if (replan_pending(e->hint + 8) > 0) { int rc = run_replans(e); if (rc) return rc; }
+    if (e->dist_world > 1) {
+      // every rank sees the same work lists (as sets): plan this rank's share, then trade results - also when this
+      // rank has nothing to plan, the exchange is collective
+      HIPOK(hipMemcpyAsync(e->hcnt, d.cnt, sizeof(DevCnt), hipMemcpyDeviceToHost, st));
+      HIPOK(hipStreamSynchronize(st));
+      const DevCnt before = *e->hcnt;
+      const int n_all = replan_pending(e->hint + 8);
+      if (n_all > e->cap_owned) { const int nc = n_all * 2 + 1024; int rc = regrow(e, &e->owned_list, 0, (size_t)nc); if (rc) return rc; e->cap_owned = nc; }
+      if (n_all > 0) { int rc = run_replans(e); if (rc) return rc; }
+      int rc = exchange_replans(e, before);
+      if (rc) return rc;
+    } else if (replan_pending(e->hint + 8) > 0) { int rc = run_replans(e); if (rc) return rc; }
     if (svc_on) {
       // on_target_reached inside step_decide for vehicles that stay on the grid (vehicle_base.py:657-661): apply the
       // flag changes now that no decider can see them half-way, then the host part in decide order
@@ -1374,6 +1495,15 @@ int ts_counters(ts_handle e, TsCounters* out) {
   int rc = sync_counters(e);
   if (rc) return rc;
   *out = e->C;
+  return TS_OK;
+}
+
+int ts_set_replan_sharding(ts_handle e, int32_t rank, int32_t world, ts_exchange_fn fn, void* user) {
+  if (!e || world < 1 || rank < 0 || rank >= world) return TS_E_INVALID;
+  if (world > 1 && !fn) return fail(e, TS_E_INVALID, "sharded replans need an exchange callback");
+  if (world > 1 && (!e->svc.empty() || e->gen.armed || e->rain_manager))
+    return fail(e, TS_E_UNSUPPORTED, "sharded replans carry closed populations (no traffic generator, service fleet or rain manager yet)");
+  e->dist_rank = rank; e->dist_world = world; e->dist_fn = world > 1 ? fn : nullptr; e->dist_user = user;
   return TS_OK;
 }
 

@@ -645,7 +645,7 @@ __global__ void k_spawn(Dev d, TsParams P, SpawnArgs a, int n, int vid0, int act
   d.over_dur[vid] = -1; d.det_dur[vid] = -1; d.next_in_cell[vid] = -1;
   d.base_speed[vid] = 0; d.cur_speed[vid] = 0; d.max_steps[vid] = 0; d.dir[vid] = -1; d.pop[vid] = (int8_t)a.pop[i];
   d.flags[vid] = VF_ALIVE; d.depart[vid] = P.enable_traffic ? elapsed : 0.0;
-  d.ev[vid] = 0; d.st_before[vid] = 0; d.st_after[vid] = 0; d.tier_hint[vid] = 0;
+  d.ev[vid] = 0; d.st_before[vid] = 0; d.st_after[vid] = 0; d.tier_hint[vid] = 0; d.chg[vid] = 0;
   if (amap_live) {   // keep the A* snapshot current: the spawn-time planners of this batch run on it
     int x, y;
     cell_xy(d, pos, x, y);

@@ -1,6 +1,11 @@
-"""One process per GPU.  The hot path has no exchange step in the bit-exact mode ("replicas only",
-DESIGN.md §6): every rank simulates an independent world; the only collectives are the barrier and the
-two reductions of the measurement (max time, summed agent-steps)."""
+"""One process per GPU (torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" on CPU).
+
+Two multi-GPU modes, both bit-exact against the sequential reference:
+  * replicas: every rank simulates an independent world; the only collectives are the barrier and the two reductions
+    of the measurement (max time, summed agent-steps) - `aggregate`;
+  * replicated state / sharded replans: every rank holds the SAME world and is stepped with the same calls; each tick's
+    replanning searches (99 % of a default-policy tick) are split over the ranks and the results are all-gathered -
+    `ShardedReplans` below is the exchange step the engine calls once per tick (`ts_set_replan_sharding`)."""
 from __future__ import annotations
 
 import os
@@ -37,3 +42,81 @@ def aggregate(elapsed_s: float, agent_steps: int, world: int, device="cpu"):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return float(t.item()), int(s.item())
+
+
+class ShardedReplans:
+    """The all-gather the engine calls once per tick in the replicated-state mode.
+
+    `ts_exchange_fn` contract (include/trafficsim.h): variable-size byte buffers in host memory, one per rank, gathered
+    into `world` slots of equal stride.  Over torch.distributed that is an all_gather of the sizes followed by an
+    all_gather of the buffers padded to the largest; with backend "nccl" the buffers are staged through the rank's GPU
+    (RCCL moves them over xGMI), with "gloo" they stay on the host.
+
+        sr = ShardedReplans(group=None)          # after init_process_group
+        sr.attach(api)                           # api: _capi.CApi bound to the HIP library, one per rank
+        api.step(n)                              # every rank the same calls
+    """
+
+    def __init__(self, group=None, device=None, all_gather=None, rank=None, world=None):
+        self.group = group
+        self.device = device
+        self.bytes_sent = 0
+        self.calls = 0
+        self._keep = None
+        self._sizes = None
+        self._cb = None
+        if all_gather is not None:      # injected collective (tests): all_gather(list_out, tensor_in)
+            self._all_gather = all_gather
+            self.rank, self.world = int(rank), int(world)
+        else:
+            import torch.distributed as dist
+            self._all_gather = lambda out, t: dist.all_gather(out, t, group=self.group)
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    # the collective on numpy byte arrays: returns (stacked (world, stride) uint8 array, sizes)
+    def gather_bytes(self, payload):
+        import numpy as np
+        import torch
+        dev = self.device if self.device is not None else "cpu"
+        n = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        self._all_gather(sizes, n)
+        sizes = [int(x.item()) for x in sizes]
+        stride = max(max(sizes), 1)
+        buf = torch.zeros(stride, dtype=torch.uint8)
+        if len(payload):
+            buf[:len(payload)] = torch.from_numpy(np.frombuffer(payload, dtype=np.uint8).copy())
+        buf = buf.to(dev)
+        out = [torch.empty(stride, dtype=torch.uint8, device=dev) for _ in range(self.world)]
+        self._all_gather(out, buf)
+        stacked = torch.stack(out).cpu().contiguous().numpy()
+        self.bytes_sent += len(payload)
+        self.calls += 1
+        return stacked, sizes
+
+    def _callback(self, user, send, nbytes, recv_pp, sizes_pp, stride_p):
+        import ctypes as C
+        import numpy as np
+        try:
+            payload = C.string_at(send, nbytes) if nbytes > 0 else b""
+            stacked, sizes = self.gather_bytes(payload)
+            self._keep = stacked                                # owned by us until the next call
+            self._sizes = (C.c_int64 * self.world)(*sizes)
+            recv_pp[0] = stacked.ctypes.data
+            sizes_pp[0] = C.cast(self._sizes, C.c_void_p).value
+            stride_p[0] = stacked.shape[1]
+            return 0
+        except Exception as ex:      # never let an exception cross the C boundary
+            import sys
+            print(f"[ShardedReplans] exchange failed on rank {self.rank}: {ex!r}", file=sys.stderr, flush=True)
+            return -1
+
+    def attach(self, api):
+        """Switch `api`'s engine to sharded replans over this group (world 1 = plain single-GPU stepping)."""
+        from . import _capi as capi
+        if self.world == 1:
+            api.set_replan_sharding(0, 1, None)
+            return self
+        self._cb = capi.EXCHANGE_FN(self._callback)
+        api.set_replan_sharding(self.rank, self.world, self._cb)
+        return self
