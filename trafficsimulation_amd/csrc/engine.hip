@@ -54,6 +54,10 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   rc = ensure_amap(e);
   if (rc) return rc;
   if (!e->density_valid) { rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
+  // room in the path pool for what these replans will write (a planner that finds the pool full throws its searches
+  // away and is run again): 128 words = 2048 path cells per entry, garbage-collecting / growing the pool if need be
+  rc = pool_make_room(e, (size_t)replan_pending(e->hint + 8) * 128 + (1u << 20));
+  if (rc) return rc;
   while (replan_pending(e->hint + 8) > 0) {
     const int n = replan_pending(e->hint + 8);
     const int grid = std::min(n, e->slots.n_slots);
