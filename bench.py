@@ -283,8 +283,9 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
         if os.path.exists(pmc_path):
             pj = json.load(open(pmc_path))
-            if pj.get("command_config") == [args.size, args.vehicles, args.policy] and dom in pj.get("kernels", {}):
-                pk = pj["kernels"][dom]
+            pname = {"k_decide_replan": "k_replan"}.get(dom, dom)     # (the profile slot keeps the round-1 name of the kernel family)
+            if pj.get("command_config") == [args.size, args.vehicles, args.policy] and pname in pj.get("kernels", {}):
+                pk = pj["kernels"][pname]
                 traffic = (2.0 * pk["fetch_kb_avg"] + pk["write_kb_avg"]) * 1024.0
         host_keys = [k for k in prof if k.startswith("host_")]
         out = {

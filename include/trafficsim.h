@@ -116,6 +116,12 @@ typedef struct TsParams {
   int32_t rain_cooldown;                             /* RAIN_COOLDOWN = 86400 (seconds; dead code in the reference) */
   int32_t rain_spawn_offset;                         /* RAIN_SPAWN_OFFSET = 10 */
   double rain_spawn_chance;                          /* RAIN_SPAWN_CHANCE = 0.1 */
+  /* _despawn_check (vehicle_base.py:695-706): a vehicle whose stuck_ticks reach the threshold (the smaller one on an
+   * intersection cell) leaves the model at the end of its step and counts as errored_internal / errored_through */
+  int32_t stuck_despawn_enabled;                     /* VEHICLE_STUCK_DESPAWN_ENABLED = False */
+  int32_t stuck_despawn_threshold;                   /* VEHICLE_STUCK_DESPAWN_THRESHOLD = 3600 */
+  int32_t stuck_despawn_threshold_intersection;      /* VEHICLE_STUCK_DESPAWN_THRESHOLD_INTERSECTION = 20 */
+  int32_t pad1_;
 } TsParams;
 
 /* Static maps produced by world-gen (`_build_simple_maps`, city_model.py:2151-2199). */

@@ -835,7 +835,16 @@ void vehicle_step(E* e, int vid) {
     }
   }
   if (v.pos == v.target) on_target_reached(e, vid);
-  // _despawn_check (695-706): VEHICLE_STUCK_DESPAWN_ENABLED = False (config.py:315); not restated.
+  // _despawn_check (695-706).  A vehicle on_target_reached has just removed has pos None: not on an intersection, and
+  // removing it a second time raises in the reference - it cannot have both arrived by moving and be stuck that long.
+  if (e->P.stuck_despawn_enabled && v.alive) {
+    const int thr = e->intersection[v.pos] == 1 ? e->P.stuck_despawn_threshold_intersection : e->P.stuck_despawn_threshold;
+    if (v.stuck_ticks >= thr) {
+      if (v.is_stuck) { e->C.stuck--; v.is_stuck = false; }
+      if (v.pop_type == TS_POP_INTERNAL) e->C.errored_internal++; else e->C.errored_through++;
+      remove_vehicle(e, vid);
+    }
+  }
 }
 
 
@@ -1396,6 +1405,7 @@ void tso_default_params(TsParams* p) {
   p->enable_traffic = 1; p->time_per_step_seconds = 6; p->eager_density = 0;
   p->rain_radius_min = 50; p->rain_radius_max = 100; p->rain_occurrences_max = 3; p->rain_cooldown = 86400;
   p->rain_spawn_offset = 10; p->rain_spawn_chance = 0.1;
+  p->stuck_despawn_enabled = 0; p->stuck_despawn_threshold = 3600; p->stuck_despawn_threshold_intersection = 20;
 }
 
 int tso_create(const TsWorld* w, const TsParams* params, ts_handle* out) {

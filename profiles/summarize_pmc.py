@@ -52,7 +52,14 @@ def main():
         fv, wv = f.get(k, []), w.get(k, [])
         out[k] = dict(launches=len(fv), fetch_kb_avg=sum(fv) / max(len(fv), 1), fetch_kb_max=max(fv) if fv else 0.0,
                       write_kb_avg=sum(wv) / max(len(wv), 1), write_kb_max=max(wv) if wv else 0.0)
+    if len(sys.argv) > 5:      # round-2 layout: bench.py reads `kernels` when `command_config` = [size, vehicles, policy] matches its run
+        size, vehicles, policy = sys.argv[5].split(",")
+        out = {"command": "python3 bench.py --no-cpu-baseline (full-policy leg + the config2 / lights secondary legs, one process)",
+               "command_config": [int(size), int(vehicles), policy],
+               "note": "KB per launch as rocprofv3 reports them; bench.py doubles FETCH_SIZE (gfx950: 128-B requests tallied at 64 B)",
+               "kernels": out}
     json.dump(out, open(sys.argv[4], "w"), indent=1)
+    out = out.get("kernels", out)
     print(json.dumps({k: v for k, v in out.items() if k.startswith("k_move") or k.startswith("k_decide")}, indent=1))
 
 

@@ -73,6 +73,10 @@ SCENARIOS = {
                                    "VEHICLE_MALFUNCTION_DURATION": 25,
                                    "VEHICLE_SIDESWIPE_COLLISION_CHANCE": 0.2,
                                    "VEHICLE_SIDESWIPE_COLLISION_DURATION": 30}),
+    # _despawn_check (vehicle_base.py:695-706) switched on with low thresholds: stuck vehicles leave mid-run (errored_* counters)
+    "despawn_96_s25": dict(size=96, seed=25, vehicles=260, ticks=140,
+                           defaults={**CLOSED, "VEHICLE_STUCK_DESPAWN_ENABLED": True, "VEHICLE_STUCK_DESPAWN_THRESHOLD": 14,
+                                     "VEHICLE_STUCK_DESPAWN_THRESHOLD_INTERSECTION": 4}),
     # config-5 style: sub-block roads + L-shaped carves
     "carve_96_s10": dict(size=96, seed=10, vehicles=200, ticks=60,
                          defaults={**CLOSED}, model_kwargs=dict(carve_subblock_roads=True)),

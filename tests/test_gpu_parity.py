@@ -7,7 +7,7 @@ import pytest
 
 from trafficsimulation_amd import _capi as capi
 from trafficsimulation_amd.world import load_trace
-from tests.trace_util import CLOSED_TRACES, DEFAULT_TRACES, DTA_TRACES, RAIN_TRACES, RECT_TRACES, SERVICE_TRACES, VARIANT_TRACES, check_initial, replay_and_compare, setup_from_trace, trace_path
+from tests.trace_util import CLOSED_TRACES, DEFAULT_TRACES, DTA_TRACES, RAIN_TRACES, RECT_TRACES, SERVICE_TRACES, VARIANT_TRACES, DESPAWN_TRACES, check_initial, replay_and_compare, setup_from_trace, trace_path
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +20,7 @@ def hip():
     api.close()
 
 
-@pytest.mark.parametrize("name", CLOSED_TRACES + DTA_TRACES + RAIN_TRACES + SERVICE_TRACES + RECT_TRACES + DEFAULT_TRACES + VARIANT_TRACES)
+@pytest.mark.parametrize("name", CLOSED_TRACES + DTA_TRACES + RAIN_TRACES + SERVICE_TRACES + RECT_TRACES + DEFAULT_TRACES + VARIANT_TRACES + DESPAWN_TRACES)
 def test_hip_reproduces_reference_trace(hip, name):
     """Every closed-population trace captured from the reference: car-following, the light controllers, the
     full replanning policy (GPU A*, phases 0-4), frequent strandings, sub-block roads, and the traffic generator

@@ -27,6 +27,7 @@ SERVICE_TRACES = ["service_64_s15", "service_heavy_96_s16", "config1_64_s11", "c
 RECT_TRACES = ["rect_96x64_s18", "rect_64x112_s19"]   # non-square grids, every subsystem on
 # constructor variants under a live run; captured after this round's GPU budget was spent, so far replayed on the oracle only
 VARIANT_TRACES = ["unopt_96_s21", "ring_r1_112_s22", "noring_96_s23", "fwdrange_96_s24"]
+DESPAWN_TRACES = ["despawn_96_s25"]                    # VEHICLE_STUCK_DESPAWN_ENABLED with low thresholds: _despawn_check fires
 DEFAULT_TRACES = ["default_200_s20"]                   # CityModel() as the reference ships: 200 x 200, config.py untouched
 
 
@@ -114,7 +115,7 @@ def replay_and_compare(api, tr, ticks=None, check_rng=True, check_counters=True)
             names = tr["cnt_fields"]
             wantc = dict(zip(names, tr["cnt_rows"][t]))
             for nme in ("stuck", "collisions", "malfunctions", "overtaking", "in_stuck_detour", "parked",
-                        "live_through", "count_completed_through", "total_distance_through",
+                        "live_through", "count_completed_through", "total_distance_through", "errored_internal", "errored_through",
                         "live_service_food", "live_service_waste", "created_service_food", "created_service_waste"):
                 if nme in wantc:
                     assert getattr(c, nme) == wantc[nme], f"{ctx}: counter {nme}: {getattr(c, nme)} != {wantc[nme]}"

@@ -41,7 +41,10 @@ constexpr int A_INF = 0x3F3F3F3F;
 constexpr int MAXB = 64;  // longest contraflow bypass (VEHICLE_MAX_CONTRAFLOW_*_STEPS <= 64)
 enum { DV_DONE = 0, DV_DEFER = 1, DV_OVERFLOW = 2, DV_POOL_FULL = 3 };
 
-constexpr int LDS_HEAP = 2048;            // heap slots (and dir bytes) a searcher keeps in LDS: 18 KB, eight searchers per CU
+#ifndef TS_LDS_HEAP
+#define TS_LDS_HEAP 2048
+#endif
+constexpr int LDS_HEAP = TS_LDS_HEAP;            // heap slots (and dir bytes) a searcher keeps in LDS: 18 KB, eight searchers per CU
                                           // (two per SIMD; the deepest heap seen on 1024^2 / 2048^2 runs is ~1500 entries)
 struct __attribute__((aligned(8))) HQ { int32_t f, i; };             // heap entry: f_arr, i_arr (g_arr / s_arr: see above)
 struct __attribute__((aligned(8))) TEnt { int32_t dist; uint32_t meta; };   // meta = stamp << 14 | steps << 2 | came-from direction

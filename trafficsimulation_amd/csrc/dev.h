@@ -39,6 +39,7 @@ struct DevCnt {
   int replan_n[8]; // replanning work queue: [0..3] class list lengths, [4] pool-full retries, [5] queue cursor, [6] entries this rank planned
   unsigned long long pool_used;  // words handed out from the path pool (device-side bump allocator)
   long long astar_calls, astar_exp, astar_relax;
+  long long errored_internal, errored_through;   // _despawn_check removals
   int pend_n[2];   // lengths of the two ping-pong lists of still-unresolved schedule slots
   unsigned int rng_event;   // first (vehicle index * 2 + is_collision) whose draw fired this pass, 0xFFFFFFFF = none
   unsigned int rng_tot[2];  // pass 1 totals: fixed words, number of speed rolls

@@ -133,7 +133,7 @@ __global__ void k_move_claim(Dev d, TsParams P, int n_sched, uint32_t prefix, co
     if (f & VF_SERVICING) return;   // ServiceVehicleAgent.step only counts down (vehicle_service.py:43-49)
     if (f & VF_EARLY) {
       if (d.G > 0 && P.light_algorithm != TS_LIGHTS_DISABLED) claim(d, pos, 3, key);  // tick_stuck reads stop[pos]
-      if (pos == d.target[vid]) claim(d, pos, 0, key);
+      if (pos == d.target[vid] || P.stuck_despawn_enabled) claim(d, pos, 0, key);   // it may leave: occupancy[pos] = 0
     } else {
       const int m = d.max_steps[vid];
       claim(d, pos, 0, key);
@@ -195,6 +195,20 @@ __device__ __forceinline__ void cell_append(const Dev& d, int cell, int vid) {
   d.next_in_cell[h] = vid;
 }
 
+// CityModel.remove_vehicle (city_model.py:1920-1941): off the maps, the cell list, the schedule and the decide order
+__device__ __forceinline__ void remove_vehicle_dev(const Dev& d, int vid, int s, int pos, uint16_t& f, int key) {
+  set_occ(d, pos, 0); d.cell[pos].stuck = 0;
+  cell_unlink(d, pos, vid);
+  f &= ~VF_ALIVE;
+  d.sched_kind[s] = K_DEAD;
+  d.active[d.active_idx[vid]] = -1;
+  int pop = d.pop[vid];
+  if (pop == TS_POP_INTERNAL) atomicAdd((unsigned long long*)&d.cnt->live_internal, (unsigned long long)-1LL);
+  else if (pop == TS_POP_THROUGH) atomicAdd((unsigned long long*)&d.cnt->live_through, (unsigned long long)-1LL);
+  atomicAdd(&d.cnt->deaths, 1);
+  if (f & VF_SVC) svc_record(d, key, vid, AR_DESPAWN);
+}
+
 // on_target_reached (vehicle_base.py:755-775) -> _despawn -> CityModel.remove_vehicle (city_model.py:1920-1941)
 __device__ void on_target_reached_dev(const Dev& d, const TsParams& P, int vid, int s, int pos, uint16_t& f,
                                       double elapsed_now, int key) {
@@ -219,16 +233,7 @@ __device__ void on_target_reached_dev(const Dev& d, const TsParams& P, int vid, 
     }
   }
   if (!(f & VF_KEEP)) {
-    set_occ(d, pos, 0); d.cell[pos].stuck = 0;
-    cell_unlink(d, pos, vid);
-    f &= ~VF_ALIVE;
-    d.sched_kind[s] = K_DEAD;
-    d.active[d.active_idx[vid]] = -1;
-    int pop = d.pop[vid];
-    if (pop == TS_POP_INTERNAL) atomicAdd((unsigned long long*)&d.cnt->live_internal, (unsigned long long)-1LL);
-    else if (pop == TS_POP_THROUGH) atomicAdd((unsigned long long*)&d.cnt->live_through, (unsigned long long)-1LL);
-    atomicAdd(&d.cnt->deaths, 1);
-    if (f & VF_SVC) svc_record(d, key, vid, AR_DESPAWN);
+    remove_vehicle_dev(d, vid, s, pos, f, key);
   } else if (!(f & VF_PARKED)) {
     f |= VF_PARKED;
     atomicAdd((unsigned long long*)&d.cnt->parked, 1ULL);
@@ -316,6 +321,16 @@ __device__ __forceinline__ void vehicle_step_dev(const Dev& d, const TsParams& P
     }
   }
   if (pos == d.target[vid]) on_target_reached_dev(d, P, vid, s, pos, f, elapsed_now, key);
+  // _despawn_check (vehicle_base.py:695-706); a vehicle that has just been removed is not checked again
+  if (P.stuck_despawn_enabled && (f & VF_ALIVE)) {
+    const int thr = st_inter(d.cell[pos].stat) == 1 ? P.stuck_despawn_threshold_intersection : P.stuck_despawn_threshold;
+    if (d.stuck_ticks[vid] >= thr) {
+      if (f & VF_STUCK) { atomicAdd((unsigned long long*)&d.cnt->stuck, (unsigned long long)-1LL); f &= ~VF_STUCK; }
+      if (d.pop[vid] == TS_POP_INTERNAL) atomicAdd((unsigned long long*)&d.cnt->errored_internal, 1ULL);
+      else atomicAdd((unsigned long long*)&d.cnt->errored_through, 1ULL);
+      remove_vehicle_dev(d, vid, s, pos, f, key);
+    }
+  }
   d.flags[vid] = f;
 }
 
@@ -474,7 +489,7 @@ __global__ void k_move_resolve(Dev d, TsParams P, int n_sched, uint32_t prefix, 
     } else if (f & VF_EARLY) {
       const uint4 cl = fast ? claims[0] : *reinterpret_cast<const uint4*>(&d.cell[pos]);
       if (lights && claim_rank(cl.z, prefix) < r) safe = false;
-      if (pos == d.target[vid] && (claim_rank(cl.x, prefix) < r || claim_rank(cl.y, prefix) < r)) safe = false;
+      if ((pos == d.target[vid] || P.stuck_despawn_enabled) && (claim_rank(cl.x, prefix) < r || claim_rank(cl.y, prefix) < r)) safe = false;
     } else if (fast) {
 #pragma unroll
       for (int k = 0; k <= MOVE_MAX; k++) {
