@@ -42,9 +42,14 @@ constexpr int MAXB = 64;  // longest contraflow bypass (VEHICLE_MAX_CONTRAFLOW_*
 enum { DV_DONE = 0, DV_DEFER = 1, DV_OVERFLOW = 2, DV_POOL_FULL = 3 };
 
 #ifndef TS_LDS_HEAP
-#define TS_LDS_HEAP 2048
+#define TS_LDS_HEAP 1024
 #endif
-constexpr int LDS_HEAP = TS_LDS_HEAP;            // heap slots (and dir bytes) a searcher keeps in LDS: 18 KB, eight searchers per CU
+constexpr int LDS_HEAP = TS_LDS_HEAP;
+// register budget of the replanning kernel and the functions it calls: at least this many waves per SIMD
+#ifndef TS_REPLAN_WAVES
+#define TS_REPLAN_WAVES 4
+#endif
+#define TS_REPLAN_OCC __attribute__((amdgpu_waves_per_eu(TS_REPLAN_WAVES, 8)))            // heap slots (and dir bytes) a searcher keeps in LDS: 18 KB, eight searchers per CU
                                           // (two per SIMD; the deepest heap seen on 1024^2 / 2048^2 runs is ~1500 entries)
 struct __attribute__((aligned(8))) HQ { int32_t f, i; };             // heap entry: f_arr, i_arr (g_arr / s_arr: see above)
 struct __attribute__((aligned(8))) TEnt { int32_t dist; uint32_t meta; };   // meta = stamp << 14 | steps << 2 | came-from direction
@@ -155,7 +160,7 @@ template <bool SPILL> __device__ __forceinline__ void hd_put(gi8p gd, int k, int
 // a fresh epoch for the searcher's table (cleared by the wave when the 18-bit stamp wraps)
 __device__ __forceinline__ uint32_t next_epoch(const Dev& d, AScratch& S) {
   if (S.epoch >= T_STAMP_MAX) {
-    const size_t n = (size_t)d.W8 * d.H8 * 64;
+    const size_t n = (size_t)max(d.n_nodes, 1);
     for (size_t q = lane_id(); q < n; q += 64) S.tab[q] = TEnt{0, 0u};
     S.epoch = 0;
     __syncthreads();
@@ -169,7 +174,7 @@ struct ACtx {
   u64 w_magic;
   gu64p gq, tab;
   gi8p gd;
-  const TS_GLOBAL uint16_t* amap;
+  const TS_GLOBAL u64* amap;
   const TS_GLOBAL float* density;
   gi32p outg;
   int heap_cap, out_cap, start_idx, goal_idx, gx, gy, maximum_steps;
@@ -249,9 +254,12 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     const bool inb_l = (unsigned)nx_l < (unsigned)W && (unsigned)ny_l < (unsigned)H;
     const int nidx_l = inb_l ? ny_l * W + nx_l : cur;
     const uint32_t t_l = inb_l ? C.tile_ix(nx_l, ny_l) : C.tile_ix(cx, cy);
-    const uint32_t a_l = C.amap[t_l];
-    const u64 e_l = tab[t_l];
+    // round 1: the map entries (flags + search-node number); round 2, issued half-way through the sift-down: the table
+    // records of those nodes
+    const u64 am_l = C.amap[t_l];
     const float dens_l = C.density[nidx_l];      // (read whether or not the search is soft: no branch around a load)
+    u64 e_l = 0;
+    bool e_loaded = false;
     KP(1);
     if (heap_size > 0) {
       const int xf = hq_f(x);
@@ -279,12 +287,20 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
         const int abs_end = uni(((idx + 1) << k) + (L - (1 << k)) - 1);
         const bool done = k < 5;
         if (done & (lane == 0)) hq_put<SPILL>(gq, abs_end, x);
+        if (!e_loaded) {                   // the first window is done: the map entries have had time to arrive
+          const uint32_t r_l = (uint32_t)(am_l >> 32);
+          e_l = tab[r_l != 0xFFFFFFFFu ? r_l : 0u];
+          e_loaded = true;
+        }
         if (done) break;
         idx = abs_end;                     // five levels down and still sinking: next window
       }
     }
     wave_mem_sync();
     KP(2);
+    const uint32_t a_l = (uint32_t)am_l, r_l = (uint32_t)(am_l >> 32);
+    const bool node_l = r_l != 0xFFFFFFFFu;
+    if (!e_loaded) e_l = tab[node_l ? r_l : 0u];     // (the heap held a single entry: no sift-down happened)
     if (cur == C.goal_idx) {
       // walk came_from back to the start, filling the output from its far end, then slide it to the front
       const gi32p outg = C.outg;
@@ -294,7 +310,8 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
         if (len >= out_cap) return AL_OVERFLOW;
         if (lane == 0) outg[out_cap - 1 - len] = c;
         len++;
-        const int dd = (int)((tab[C.tile_ix(px, py)] >> 32) & 3u);
+        const uint32_t pr = (uint32_t)(C.amap[C.tile_ix(px, py)] >> 32);
+        const int dd = (int)((tab[pr] >> 32) & 3u);
         px -= (dd == 1) - (dd == 3); py -= (dd == 0) - (dd == 2);
         c = py * W + px;
       }
@@ -311,9 +328,10 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     }
     const int g = f_top - (abs(cx - gx) + abs(cy - gy));
     const u64 e_c = rl(e_l, 4);
-    const uint32_t m_c = (uint32_t)(e_c >> 32);
+    const bool node_c = rl((int)node_l, 4) != 0;     // (only a start cell can be off the node set: dist 0, no steps)
+    const uint32_t m_c = node_c ? (uint32_t)(e_c >> 32) : (epoch << T_STAMP_SHIFT);
     {
-      const int dist_c = (m_c >> T_STAMP_SHIFT) == epoch ? (int)(uint32_t)e_c : A_INF;
+      const int dist_c = !node_c ? 0 : (m_c >> T_STAMP_SHIFT) == epoch ? (int)(uint32_t)e_c : A_INF;
       if (g > dist_c) continue;
     }
     KP(3);
@@ -336,7 +354,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
       ng_l += n_occ ? occ_pen : 0.0;
       ng_l += n_stop ? C.stop_pen : 0.0;
       ng_l += (C.rt_on & n_road) ? (rt == 1u ? C.rt1 : rt == 2u ? C.rt2 : rt == 3u ? C.rt3 : 0.0) : 0.0;
-      ok_l = (lane < 4) & inb_l & (steps + 1 <= C.maximum_steps) & (flow | (C.ignore_flow & n_road)) & (C.soft | !(n_occ | n_stop)) &
+      ok_l = (lane < 4) & inb_l & node_l & (steps + 1 <= C.maximum_steps) & (flow | (C.ignore_flow & n_road)) & (C.soft | !(n_occ | n_stop)) &
              (ng_l < (double)dist_l);
     }
     // ---- commit.  The four neighbours are distinct cells, so no relaxation changes another one's test: the table
@@ -352,7 +370,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     const int ngi_l = (int)ng_l;
     const u64 ent_l = hq_pack((int)(ng_l + (double)(abs(nx_l - gx) + abs(ny_l - gy))), nidx_l);
     if (ok_l) {
-      tab[t_l] = (u64)(uint32_t)ngi_l | ((u64)(stamp | (C.limited ? (uint32_t)(steps + 1) << 2 : 0u) | (uint32_t)dd_l) << 32);
+      tab[r_l] = (u64)(uint32_t)ngi_l | ((u64)(stamp | (C.limited ? (uint32_t)(steps + 1) << 2 : 0u) | (uint32_t)dd_l) << 32);
       hd_put<SPILL>(gd, heap_size + __builtin_popcount(relax & below_l), dd_l);
     }
     KP(5);
@@ -396,7 +414,7 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   C.gq = (gu64p)(uintptr_t)uni64((u64)(uintptr_t)S.gq);
   C.gd = (gi8p)(uintptr_t)uni64((u64)(uintptr_t)S.gd);
   C.tab = (gu64p)(uintptr_t)uni64((u64)(uintptr_t)S.tab);
-  C.amap = (const TS_GLOBAL uint16_t*)(uintptr_t)uni64((u64)(uintptr_t)d.amap);
+  C.amap = (const TS_GLOBAL u64*)(uintptr_t)uni64((u64)(uintptr_t)d.amap);
   C.density = (const TS_GLOBAL float*)(uintptr_t)uni64((u64)(uintptr_t)d.density);
   C.outg = (gi32p)(uintptr_t)uni64((u64)(uintptr_t)out);
   C.heap_cap = uni(S.heap_cap);
@@ -415,7 +433,8 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   C.xy_of(C.goal_idx, C.gx, C.gy);
   C.xy_of(C.start_idx, sx, sy);
   if (C.lane == 0) {
-    C.tab[C.tile_ix(sx, sy)] = (u64)0u | ((u64)(C.epoch << T_STAMP_SHIFT) << 32);    // dist 0, steps 0
+    const uint32_t sr = (uint32_t)(C.amap[C.tile_ix(sx, sy)] >> 32);
+    if (sr != 0xFFFFFFFFu) C.tab[sr] = (u64)0u | ((u64)(C.epoch << T_STAMP_SHIFT) << 32);    // dist 0, steps 0
     g_lq[0] = hq_pack(abs(sx - C.gx) + abs(sy - C.gy), C.start_idx);
     g_ld[0] = -1;
   }
@@ -452,7 +471,7 @@ __device__ int reach_strict_wave(const Dev& d, AScratch& S, int start, int goal)
   const u64 w_magic = uni64(d.w_magic);
   const gi32p ring = (gi32p)(uintptr_t)uni64((u64)(uintptr_t)S.gq);
   TS_GLOBAL uint32_t* const tabw = (TS_GLOBAL uint32_t*)(uintptr_t)uni64((u64)(uintptr_t)S.tab);   // record t: dist at 2t, meta at 2t + 1
-  const TS_GLOBAL uint16_t* amap = (const TS_GLOBAL uint16_t*)(uintptr_t)uni64((u64)(uintptr_t)d.amap);
+  const TS_GLOBAL u64* amap = (const TS_GLOBAL u64*)(uintptr_t)uni64((u64)(uintptr_t)d.amap);
   const unsigned qcap = (unsigned)uni(S.heap_cap - LDS_HEAP) * 2u;
   if (qcap < 256u) return 0;
   auto xy_of = [&](int cell, int& x, int& y) {
@@ -466,7 +485,8 @@ __device__ int reach_strict_wave(const Dev& d, AScratch& S, int start, int goal)
     int sx, sy;
     xy_of(start, sx, sy);
     ring[0] = start;
-    tabw[2 * (size_t)tile_ix(sx, sy) + 1] = stamp;
+    const uint32_t sr = (uint32_t)(amap[tile_ix(sx, sy)] >> 32);
+    if (sr != 0xFFFFFFFFu) tabw[2 * (size_t)sr + 1] = stamp;
   }
   __syncthreads();
   unsigned head = 0, tail = 1;
@@ -483,9 +503,10 @@ __device__ int reach_strict_wave(const Dev& d, AScratch& S, int start, int goal)
       if (bits & (1u << dd)) {
         const int nx = cx + (dd == 1) - (dd == 3), ny = cy + (dd == 0) - (dd == 2);
         if (nx >= 0 && nx < W && ny >= 0 && ny < H) {
-          const uint32_t tn = tile_ix(nx, ny);
-          if (((uint32_t)amap[tn] & 0x300u) == 0u &&
-              __hip_atomic_exchange(&tabw[2 * (size_t)tn + 1], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp)
+          const u64 an = amap[tile_ix(nx, ny)];
+          const uint32_t rn = (uint32_t)(an >> 32);
+          if (((uint32_t)an & 0x300u) == 0u && rn != 0xFFFFFFFFu &&
+              __hip_atomic_exchange(&tabw[2 * (size_t)rn + 1], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp)
             n = ny * W + nx;
         }
       }
@@ -1009,7 +1030,7 @@ __device__ __attribute__((noinline)) int replan_turn(const Dev& d, const TsParam
 // full go to `retry_list` (counter replan_n[4]); replan_n[5] is the queue cursor.
 // `world` > 1: the replicated-state multi-GPU mode - this rank plans only the vehicles whose decide-order index is
 // congruent to `rank`; the results travel through ts_replan_export / ts_replan_import.
-__global__ void __launch_bounds__(64) k_replan(Dev d, TsParams P, ASlots sl, RLists lists, int32_t* retry_list, int rank, int world,
+TS_REPLAN_OCC __global__ void __launch_bounds__(64) k_replan(Dev d, TsParams P, ASlots sl, RLists lists, int32_t* retry_list, int rank, int world,
                                                int32_t* owned_list) {
   AScratch S;
   scratch_bind(sl, blockIdx.x, S);
@@ -1092,7 +1113,7 @@ __global__ void k_replan_import(Dev d, const ReplanRec* recs, int n, const uint3
 }
 
 // one search on the current maps (the `astar(...)` operator seam, ts_astar) - searcher slot 0
-__global__ void __launch_bounds__(64) k_astar_single(Dev d, TsParams P, ASlots sl, int start_idx, int goal_idx, int soft,
+TS_REPLAN_OCC __global__ void __launch_bounds__(64) k_astar_single(Dev d, TsParams P, ASlots sl, int start_idx, int goal_idx, int soft,
                                                       int ignore_flow, int maximum_steps, int32_t* out_len) {
   if (blockIdx.x) return;
   AScratch S;
@@ -1115,7 +1136,7 @@ __global__ void __launch_bounds__(64) k_astar_single(Dev d, TsParams P, ASlots s
 
 // VehicleAgent.__init__ -> self.path = self._compute_path() on a cache miss (vehicle_base.py:80-81, 143-167):
 // the phase 0-4 planner for a freshly placed vehicle.  status: path length, or -1 overflow / -2 pool full.
-__global__ void __launch_bounds__(64) k_spawn_plan(Dev d, TsParams P, ASlots sl, int vid, int32_t* status) {
+TS_REPLAN_OCC __global__ void __launch_bounds__(64) k_spawn_plan(Dev d, TsParams P, ASlots sl, int vid, int32_t* status) {
   if (blockIdx.x) return;
   const bool one = threadIdx.x == 0;
   AScratch S;

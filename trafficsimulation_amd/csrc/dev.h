@@ -93,9 +93,12 @@ struct Dev {
   uint8_t* tier_hint;  // per vehicle: cost class (0..3) of its last replan, orders the replanning work queue
   uint8_t* chg;        // per vehicle: what its replan of this tick rewrote (bit 0 path, bits 1-4 aux paths) - read and cleared by
                        // k_replan_export in the multi-GPU mode
-  // what a search reads about a cell, as of the last tick start (or the last ensure_amap): static byte | occupied << 8 |
-  // red << 9, in tiled order - one 128-byte line per 8 x 8 tile
-  uint16_t* amap;
+  // what a search reads about a cell, as of the last tick start (or the last ensure_amap), in tiled order: low word =
+  // static byte | occupied << 8 | red << 9, high word = the cell's search-node number (0xFFFFFFFF: not a node).  Nodes
+  // are the cells a search can ever stand on (roads, cells with flow bits, cells a flow bit points at), numbered in
+  // tiled order: a searcher's dist / came_from table has one record per NODE, a quarter of one record per cell.
+  unsigned long long* amap;
+  int n_nodes;
   float* density;    // _update_density_map (city_model.py:1764-1778), materialised on demand
   int8_t* occ_snap;  // occupancy at the last tick start (what density_map is a function of)
   // ordered lists

@@ -797,7 +797,36 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   ok &= hipMemcpyAsync(d.is_road, w->is_road_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
   ok &= hipMemcpyAsync(t_road_type, w->road_type_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
   ok &= hipMemcpyAsync(t_inter, w->intersection_map, N, hipMemcpyHostToDevice, st) == hipSuccess;
-  hipLaunchKernelGGL(k_cells_init, dim3(nblk((long long)N)), dim3(BLK), 0, st, d.cell, (int)N, t_allowed, d.is_road, t_road_type, t_inter);
+  // search nodes: every cell a search can stand on - roads, cells with flow bits, cells a neighbour's flow bit points at
+  // - numbered in the 8 x 8-tiled order of the A* snapshot
+  int32_t* t_node = nullptr;
+  {
+    const int W = e->W, H = e->H;
+    std::vector<uint8_t> is_node(N, 0);
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        const size_t c = (size_t)y * W + x;
+        const int a = w->allowed_dirs_map[c] & 15;
+        if (w->is_road_map[c] == 1 || a) is_node[c] = 1;
+        if ((a & 1) && y + 1 < H) is_node[c + W] = 1;
+        if ((a & 2) && x + 1 < W) is_node[c + 1] = 1;
+        if ((a & 4) && y > 0) is_node[c - W] = 1;
+        if ((a & 8) && x > 0) is_node[c - 1] = 1;
+      }
+    std::vector<int32_t> node(N, -1);
+    int n_nodes = 0;
+    for (int ty = 0; ty < d.H8; ty++)
+      for (int tx = 0; tx < d.W8; tx++)
+        for (int yy = 0; yy < 8; yy++)
+          for (int xx = 0; xx < 8; xx++) {
+            const int x = tx * 8 + xx, y = ty * 8 + yy;
+            if (x < W && y < H && is_node[(size_t)y * W + x]) node[(size_t)y * W + x] = n_nodes++;
+          }
+    d.n_nodes = n_nodes;
+    if (hipMalloc((void**)&t_node, N * 4) != hipSuccess) { (void)hipFree(t_allowed); (void)hipFree(t_road_type); (void)hipFree(t_inter); return bail(TS_E_DEVICE); }
+    ok &= hipMemcpy(t_node, node.data(), N * 4, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  hipLaunchKernelGGL(k_cells_init, dim3(nblk((long long)N)), dim3(BLK), 0, st, d.cell, (int)N, t_allowed, d.is_road, t_road_type, t_inter, t_node);
   uint32_t table[256];
   for (uint32_t i = 0; i < 256; i++) {
     uint32_t c = i;
@@ -809,7 +838,7 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   ok &= hipHostMalloc((void**)&e->hint, sizeof(int) * 16) == hipSuccess;
   { int* hd = nullptr; ok &= hipHostMalloc((void**)&hd, sizeof(int) * 64) == hipSuccess; if (hd) memset(hd, 0, sizeof(int) * 64); d.hdbg = hd; }
   ok &= hipStreamSynchronize(st) == hipSuccess;
-  (void)hipFree(t_allowed); (void)hipFree(t_road_type); (void)hipFree(t_inter);
+  (void)hipFree(t_allowed); (void)hipFree(t_road_type); (void)hipFree(t_inter); (void)hipFree(t_node);
   if (!ok) return bail(TS_E_DEVICE);
   ok = hipHostMalloc((void**)&e->h_words, MTPipe::TW_CAP * 4) == hipSuccess;
   ok &= dalloc(e, &d.words, (size_t)MTPipe::TW_CAP) == hipSuccess;

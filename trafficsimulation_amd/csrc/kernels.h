@@ -665,7 +665,7 @@ __global__ void k_spawn(Dev d, TsParams P, SpawnArgs a, int n, int vid0, int act
     int x, y;
     cell_xy(d, pos, x, y);
     const uint32_t t = tix(d, x, y);
-    atomicOr(reinterpret_cast<unsigned int*>(d.amap) + (t >> 1), 0x100u << ((t & 1) * 16));
+    atomicOr(&d.amap[t], 0x100ull);
   }
   for (int k = 0; k < 4; k++) { d.ax_len[k][vid] = 0; d.ax_off[k][vid] = 0; d.ax_start[k][vid] = pos; }
   d.active[active0 + i] = vid; d.active_idx[vid] = active0 + i;
@@ -793,14 +793,15 @@ __global__ void k_rain_map(int8_t* rain, int W, int H, RainDiscs prev, RainDiscs
 // rank[slot] = position of the slot in the shuffled key order
 // cell records <-> byte planes
 __global__ void k_cells_init(Cell* cell, int n, const uint8_t* allowed, const int8_t* is_road, const int8_t* road_type,
-                             const int8_t* inter) {
+                             const int8_t* inter, const int32_t* node_of_cell) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   Cell x;
   x.claim[0] = x.claim[1] = x.claim[2] = x.claim[3] = 0xFFFFFFFFu;
   x.veh = -1; x.occ = 0; x.stop = 0; x.stuck = 0;
   x.stat = (uint8_t)((allowed[c] & 15) | ((is_road[c] == 1) << 4) | ((inter[c] == 1) << 5) | ((road_type[c] & 3) << 6));
-  x.pad_[0] = x.pad_[1] = 0;
+  x.pad_[0] = (uint32_t)node_of_cell[c];   // search-node number (A* snapshot, Dev::amap), 0xFFFFFFFF = none
+  x.pad_[1] = 0;
   cell[c] = x;
 }
 // the A* snapshot of the maps (Dev::amap) from the cell records
@@ -809,8 +810,9 @@ __global__ void k_amap_build(Dev d) {
   if (c >= d.N) return;
   int x, y;
   cell_xy(d, c, x, y);
-  const uint32_t dw = *reinterpret_cast<const uint32_t*>(&d.cell[c].occ);   // occ | stop << 8 | stuck << 16 | stat << 24
-  d.amap[tix(d, x, y)] = (uint16_t)((dw >> 24) | (((int8_t)(dw & 0xFF) == 1) ? 0x100u : 0u) | (((int8_t)((dw >> 8) & 0xFF) == 1) ? 0x200u : 0u));
+  const uint2 w = *reinterpret_cast<const uint2*>(&d.cell[c].occ);   // .x = occ | stop << 8 | stuck << 16 | stat << 24, .y = node number
+  const uint32_t flags = (w.x >> 24) | (((int8_t)(w.x & 0xFF) == 1) ? 0x100u : 0u) | (((int8_t)((w.x >> 8) & 0xFF) == 1) ? 0x200u : 0u);
+  d.amap[tix(d, x, y)] = (unsigned long long)flags | ((unsigned long long)w.y << 32);
 }
 __global__ void k_claims_reset(Cell* cell, int n) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
