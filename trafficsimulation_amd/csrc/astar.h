@@ -234,6 +234,11 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
   const int wadj = (lane & 1) == 0 ? 1 : 0;                       // left children (even lanes) win ties against their sibling
   unsigned long long wanc = 0;                                     // this lane's ancestors-or-self inside the window
   for (int j = 0; j < wlvl; j++) wanc |= 1ull << (lane >> j);
+  {  // pin the mask in registers: left alone, the compiler re-derives it (a six-step loop) in every turn of the main loop
+    unsigned lo = (unsigned)wanc, hi = (unsigned)(wanc >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    wanc = ((unsigned long long)hi << 32) | lo;
+  }
   const int dd_l = lane & 3;
   const int dx_l = lane < 4 ? (dd_l == 1) - (dd_l == 3) : 0, dy_l = lane < 4 ? (dd_l == 0) - (dd_l == 2) : 0;
   const unsigned below_l = (1u << lane) - 1u;                      // (lanes 0-3 use it)
