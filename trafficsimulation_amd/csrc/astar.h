@@ -181,6 +181,8 @@ struct ACtx {
   uint32_t epoch;
   bool soft, ignore_flow, limited, turn_on, rt_on, dens_on;
   double turn_pen, contra_pen, veh_pen, stop_pen, dyn_scale, rt1, rt2, rt3;
+  int turn2, contra2, veh2, stop2, rt2_1, rt2_2, rt2_3;     // the same in half units (valid when `half`)
+  bool half;
   long long n_exp, n_relax;
   int max_heap;
   long long prof[8], pt;
@@ -215,7 +217,7 @@ enum { AL_EMPTY = -2, AL_OVERFLOW = -1, AL_SWITCH = -3 };   // astar_loop result
 // SPILL = false runs while the whole heap fits LDS (straight LDS accesses); SPILL = true is the general form.  Either
 // returns AL_SWITCH when the other one should take over.
 // ---------------------------------------------------------------------------------------------
-template <bool SPILL>
+template <bool SPILL, bool HALF>
 __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
   // A lone wave issues one instruction every four cycles whatever its kind, so this loop is written for instruction
   // count: lane-parallel vector work and one ballot in place of scalar walks, no scalar <-> vector round trips that
@@ -344,7 +346,11 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     const int steps = C.limited ? (int)((m_c >> 2) & T_STEPS_MASK) : 0;
     const uint32_t bits = (uint32_t)rl((int)a_l, 4) & 15u;
     // ---- lane dd < 4 evaluates neighbour dd from what was fetched before the sift-down -------------------------
-    double ng_l = (double)(g + 1);
+    // HALF: every penalty is a non-negative multiple of 0.5 (the reference's defaults are), so the reference's float `ng`
+    // is carried exactly as an integer count of half units: ng < dist  <=>  ng2 < 2 dist, int(ng) = ng2 >> 1,
+    // int(ng + h) = (ng2 >> 1) + h.  Otherwise the same in doubles.
+    double ng_l = 0.0;
+    int ng2_l = 0;
     bool ok_l;
     {
       const uint32_t m_l = (uint32_t)(e_l >> 32);
@@ -352,15 +358,32 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
       const bool n_occ = ((a_l >> 8) & 1u) != 0u, n_stop = ((a_l >> 9) & 1u) != 0u, n_road = ((a_l >> 4) & 1u) != 0u;
       const uint32_t rt = (a_l >> 6) & 3u;
       const bool flow = ((bits >> dd_l) & 1u) != 0u;
+      const bool turn = C.turn_on & (prev_dir != -1) & (dd_l != prev_dir);
+      bool cheaper;
       // (selects, not branches: a killed neighbour's cost is simply not used)
-      ng_l += (C.turn_on & (prev_dir != -1) & (dd_l != prev_dir)) ? C.turn_pen : 0.0;
-      ng_l += flow ? 0.0 : C.contra_pen;
-      const double occ_pen = C.dens_on ? __builtin_trunc(C.veh_pen * (1.0 + C.dyn_scale * (double)dens_l)) : C.veh_pen;
-      ng_l += n_occ ? occ_pen : 0.0;
-      ng_l += n_stop ? C.stop_pen : 0.0;
-      ng_l += (C.rt_on & n_road) ? (rt == 1u ? C.rt1 : rt == 2u ? C.rt2 : rt == 3u ? C.rt3 : 0.0) : 0.0;
-      ok_l = (lane < 4) & inb_l & node_l & (steps + 1 <= C.maximum_steps) & (flow | (C.ignore_flow & n_road)) & (C.soft | !(n_occ | n_stop)) &
-             (ng_l < (double)dist_l);
+      if constexpr (HALF) {
+        int n2 = 2 * (g + 1);
+        n2 += turn ? C.turn2 : 0;
+        n2 += flow ? 0 : C.contra2;
+        const int dyn2 = 2 * (int)__builtin_trunc(C.veh_pen * (1.0 + C.dyn_scale * (double)dens_l));
+        const int occ2 = C.dens_on ? dyn2 : C.veh2;
+        n2 += n_occ ? occ2 : 0;
+        n2 += n_stop ? C.stop2 : 0;
+        const int rtp = rt == 1u ? C.rt2_1 : rt == 2u ? C.rt2_2 : rt == 3u ? C.rt2_3 : 0;
+        n2 += (C.rt_on & n_road) ? rtp : 0;
+        ng2_l = n2;
+        cheaper = n2 < 2 * dist_l;
+      } else {
+        ng_l = (double)(g + 1);
+        ng_l += turn ? C.turn_pen : 0.0;
+        ng_l += flow ? 0.0 : C.contra_pen;
+        const double occ_pen = C.dens_on ? __builtin_trunc(C.veh_pen * (1.0 + C.dyn_scale * (double)dens_l)) : C.veh_pen;
+        ng_l += n_occ ? occ_pen : 0.0;
+        ng_l += n_stop ? C.stop_pen : 0.0;
+        ng_l += (C.rt_on & n_road) ? (rt == 1u ? C.rt1 : rt == 2u ? C.rt2 : rt == 3u ? C.rt3 : 0.0) : 0.0;
+        cheaper = ng_l < (double)dist_l;
+      }
+      ok_l = (lane < 4) & inb_l & node_l & (steps + 1 <= C.maximum_steps) & (flow | (C.ignore_flow & n_road)) & (C.soft | !(n_occ | n_stop)) & cheaper;
     }
     // ---- commit.  The four neighbours are distinct cells, so no relaxation changes another one's test: the table
     // records and the dir bytes of all of them go out with one masked store each; only the heap pushes are made one
@@ -372,8 +395,9 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     C.n_relax += n_new;
     if (heap_size + n_new > C.heap_cap) return AL_OVERFLOW;
     C.max_heap = max(C.max_heap, heap_size + n_new);
-    const int ngi_l = (int)ng_l;
-    const u64 ent_l = hq_pack((int)(ng_l + (double)(abs(nx_l - gx) + abs(ny_l - gy))), nidx_l);
+    const int h_l = abs(nx_l - gx) + abs(ny_l - gy);
+    const int ngi_l = HALF ? (ng2_l >> 1) : (int)ng_l;
+    const u64 ent_l = hq_pack(HALF ? ngi_l + h_l : (int)(ng_l + (double)h_l), nidx_l);
     if (ok_l) {
       tab[r_l] = (u64)(uint32_t)ngi_l | ((u64)(stamp | (C.limited ? (uint32_t)(steps + 1) << 2 : 0u) | (uint32_t)dd_l) << 32);
       hd_put<SPILL>(gd, heap_size + __builtin_popcount(relax & below_l), dd_l);
@@ -428,6 +452,16 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   C.turn_pen = P.turn_penalty; C.contra_pen = P.contraflow_penalty; C.veh_pen = P.obstacle_penalty_vehicle;
   C.stop_pen = P.obstacle_penalty_stop; C.dyn_scale = P.dynamic_penalty_scale; C.rt1 = P.road_type_penalty_r1;
   C.rt2 = P.road_type_penalty_r2; C.rt3 = P.road_type_penalty_r3;
+  {
+    // half units carry the costs exactly iff every penalty is a non-negative multiple of 0.5 of moderate size
+    const double pp[7] = {C.turn_pen, C.contra_pen, C.veh_pen, C.stop_pen, C.rt1, C.rt2, C.rt3};
+    bool half = true;
+    for (int k = 0; k < 7; k++) half = half && pp[k] >= 0.0 && pp[k] < 1048576.0 && (double)(int)(pp[k] * 2.0) == pp[k] * 2.0;
+    half = half && C.dyn_scale >= 0.0 && C.dyn_scale <= 64.0;   // (2 (g + 1) + penalties stays below 2^31 for every g < INF)
+    C.half = half;
+    C.turn2 = (int)(C.turn_pen * 2.0); C.contra2 = (int)(C.contra_pen * 2.0); C.veh2 = (int)(C.veh_pen * 2.0); C.stop2 = (int)(C.stop_pen * 2.0);
+    C.rt2_1 = (int)(C.rt1 * 2.0); C.rt2_2 = (int)(C.rt2 * 2.0); C.rt2_3 = (int)(C.rt3 * 2.0);
+  }
   C.n_exp = 0; C.n_relax = 0; C.max_heap = 0;
   for (int k = 0; k < 8; k++) C.prof[k] = 0;
   C.pt = clock64();
@@ -446,11 +480,20 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   int heap_size = 1;
   wave_mem_sync();
   int r;
-  for (;;) {
-    r = astar_loop<false>(C, heap_size);
-    if (r != AL_SWITCH) break;
-    r = astar_loop<true>(C, heap_size);
-    if (r != AL_SWITCH) break;
+  if (C.half) {
+    for (;;) {
+      r = astar_loop<false, true>(C, heap_size);
+      if (r != AL_SWITCH) break;
+      r = astar_loop<true, true>(C, heap_size);
+      if (r != AL_SWITCH) break;
+    }
+  } else {
+    for (;;) {
+      r = astar_loop<false, false>(C, heap_size);
+      if (r != AL_SWITCH) break;
+      r = astar_loop<true, false>(C, heap_size);
+      if (r != AL_SWITCH) break;
+    }
   }
   S.expansions += C.n_exp; S.relaxations += C.n_relax;
   if (C.lane == 0) {   // profiling aid: deepest heap / longest search any searcher has seen (ts_debug_read words 4, 5)
