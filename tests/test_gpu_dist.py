@@ -44,7 +44,9 @@ d.destroy_process_group()
 
 
 def test_two_ranks_sharded_replans_match_the_reference():
-    traces = ["full_64_s1", "full_96_s8", "faults_64_s9", "carve_96_s10"]
+    # closed populations, then the agents that step on the host inside the shuffled order (traffic generator spawning and
+    # planning mid-tick, service vehicles with their arrival records, rain): every rank runs those redundantly
+    traces = ["full_64_s1", "full_96_s8", "faults_64_s9", "carve_96_s10", "dta_64_s12", "rain_96_s14", "config1_64_s11", "despawn_96_s25"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
         f.write(WORKER % dict(root=ROOT, traces=traces))
@@ -60,6 +62,8 @@ def test_two_ranks_sharded_replans_match_the_reference():
     for name in traces:
         a, b = r0["res"][name], r1["res"][name]
         assert a["ticks"] == b["ticks"] > 0
-        assert a["astar_calls"] == b["astar_calls"] == a["want_calls"]     # the searches of both ranks add up to the reference's
+        if name != "config1_64_s11":     # (service vehicles plan inside the generator's step too: not in the fixture's per-tick count)
+            assert a["astar_calls"] == b["astar_calls"] == a["want_calls"]     # the searches of both ranks add up to the reference's
+        assert a["astar_calls"] == b["astar_calls"]
         assert a["fp"] == b["fp"]
         assert a["exchanges"] == b["exchanges"] > 0 and a["bytes"] > 0 and b["bytes"] > 0   # both ranks planned something

@@ -1535,8 +1535,6 @@ int ts_counters(ts_handle e, TsCounters* out) {
 int ts_set_replan_sharding(ts_handle e, int32_t rank, int32_t world, ts_exchange_fn fn, void* user) {
   if (!e || world < 1 || rank < 0 || rank >= world) return TS_E_INVALID;
   if (world > 1 && !fn) return fail(e, TS_E_INVALID, "sharded replans need an exchange callback");
-  if (world > 1 && (!e->svc.empty() || e->gen.armed || e->rain_manager))
-    return fail(e, TS_E_UNSUPPORTED, "sharded replans carry closed populations (no traffic generator, service fleet or rain manager yet)");
   e->dist_rank = rank; e->dist_world = world; e->dist_fn = world > 1 ? fn : nullptr; e->dist_user = user;
   return TS_OK;
 }
