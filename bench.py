@@ -167,6 +167,9 @@ def main():
                          "replicas = independent worlds")
     ap.add_argument("--world", choices=["synthetic", "reference"], default="synthetic",
                     help="synthetic = citygen look-alike (fast to build); reference = worldgen, the reference's city for the seed")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N>1: nccl = RCCL over xGMI (one GPU per rank); gloo = host collectives, for "
+                         "rehearsing the N>1 path with several ranks on one GPU (local rank r uses device r %% visible devices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the reduced-policy legs of the N=1 line")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
@@ -201,10 +204,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
+    coll_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
     n_gpus = dist.get_world_size() if world > 1 else 1
@@ -225,7 +234,7 @@ def main():
     sharder = None
     setup(api, tables, routes, seed, policy=args.policy)
     if world > 1 and mode == "sharded":
-        sharder = tdist.ShardedReplans(device=torch.device("cuda", local_rank)).attach(api)
+        sharder = tdist.ShardedReplans(device=coll_dev if args.backend == "nccl" else None).attach(api)
     v0 = api.num_vehicles()
     t_w = time.perf_counter()
     api.step(args.warmup)
@@ -243,11 +252,11 @@ def main():
     steps_done = c1.agent_steps - c0.agent_steps
     rounds = c1.move_rounds - c0.move_rounds
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         if mode == "replicas":   # independent worlds: the job's agent-steps are the sum; sharded: every rank stepped the same world
-            ss = torch.tensor([steps_done], dtype=torch.int64, device="cuda")
+            ss = torch.tensor([steps_done], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(ss, op=dist.ReduceOp.SUM)
             steps_done = int(ss.item())
     prof = api.profile()
