@@ -121,7 +121,9 @@ typedef struct TsParams {
   int32_t stuck_despawn_enabled;                     /* VEHICLE_STUCK_DESPAWN_ENABLED = False */
   int32_t stuck_despawn_threshold;                   /* VEHICLE_STUCK_DESPAWN_THRESHOLD = 3600 */
   int32_t stuck_despawn_threshold_intersection;      /* VEHICLE_STUCK_DESPAWN_THRESHOLD_INTERSECTION = 20 */
-  int32_t pad1_;
+  /* VEHICLE_RESPECT_AWARENESS (config.py:278, astar_numba.py:29-50): occupied / red cells only count as obstacles of a
+   * search inside the field of view cast from its start cell (straight road runs, vehicle_awareness_range wide) */
+  int32_t respect_awareness;                         /* VEHICLE_RESPECT_AWARENESS = False */
 } TsParams;
 
 /* Static maps produced by world-gen (`_build_simple_maps`, city_model.py:2151-2199). */

@@ -245,6 +245,8 @@ struct ts_engine {
   // A* scratch (epoch-stamped so the O(N) init of astar_numba.py:119-122 is not repeated)
   std::vector<int> a_dist, a_came, a_epoch;
   int epoch = 0;
+  std::vector<int> fov_epoch;      // compute_fov_inplace's mask (astar_numba.py:29-50), stamped instead of reset
+  int fov_ep = 0;
   std::vector<int> hf, hg, hs, hi;
   std::vector<int8_t> hdir;
 };
@@ -351,7 +353,7 @@ void update_density_fast(E* e) {
 // ------------------------------ A* (astar_numba.py:87-239) ------------------------------------
 // Verbatim semantics incl. both quirks of SURVEY §8(a) A13: (1) dir_arr is indexed by heap SLOT and
 // is not swapped by the sift routines; (2) `ng` is a float (R1 penalty 0.5) and truncates on store.
-// respect_awareness (FOV) is off by default (config.py:278) and not restated.
+// respect_awareness (FOV, astar_numba.py:29-50; off by default, config.py:278) is restated inside astar().
 inline void heap_sift_up(E* e, int i) {
   while (i > 0) {
     int parent = (i - 1) / 2;
@@ -400,6 +402,26 @@ void astar(E* e, int sx, int sy, int gx, int gy, bool soft, bool ignore_flow, in
   auto dist_get = [&](int i) { return e->a_epoch[i] == ep ? e->a_dist[i] : INF; };
   auto dist_set = [&](int i, int d, int from) { e->a_epoch[i] = ep; e->a_dist[i] = d; e->a_came[i] = from; };
   const int start_idx = sy * W + sx, goal_idx = gy * W + gx;
+  // compute_fov_inplace(start_x, start_y, ...) (astar_numba.py:29-50, 113-115): from a line of 2 * awareness - 1 cells through
+  // the start, perpendicular to each of the four directions, rays run along the direction for as long as they stay on road
+  const bool fov_on = P.respect_awareness != 0;
+  if (fov_on) {
+    if ((int)e->fov_epoch.size() != e->N) { e->fov_epoch.assign(e->N, 0); e->fov_ep = 0; }
+    const int fe = ++e->fov_ep, aw = P.vehicle_awareness_range;
+    for (int d = 0; d < 4; d++) {
+      const int dx = DX[d], dy = DY[d], px = -dy, py = dx;
+      for (int offset = -aw + 1; offset < aw; offset++) {
+        const int x0 = sx + offset * px, y0 = sy + offset * py;
+        int step = 0, x = x0, y = y0;
+        while (x >= 0 && x < W && y >= 0 && y < H && e->is_road[y * W + x] == 1) {
+          e->fov_epoch[y * W + x] = fe;
+          step++;
+          x = x0 + dx * step; y = y0 + dy * step;
+        }
+      }
+    }
+  }
+  auto seen = [&](int i) { return !fov_on || e->fov_epoch[i] == e->fov_ep; };
   dist_set(start_idx, 0, -1);
   heap_reserve(e, 8);
   int heap_size = 1;
@@ -436,7 +458,7 @@ void astar(E* e, int sx, int sy, int gx, int gy, bool soft, bool ignore_flow, in
         if (ignore_flow && e->is_road[nidx] == 1) ng += P.contraflow_penalty;
         else continue;
       }
-      if (e->occ[nidx] == 1) {
+      if (e->occ[nidx] == 1 && seen(nidx)) {
         if (soft && P.dynamic_penalties_enabled) {
           double p = P.obstacle_penalty_vehicle;
           double local_density = (double)e->density[nidx];
@@ -444,7 +466,7 @@ void astar(E* e, int sx, int sy, int gx, int gy, bool soft, bool ignore_flow, in
         } else if (soft) ng += P.obstacle_penalty_vehicle;
         else continue;
       }
-      if (e->stop[nidx] == 1) {
+      if (e->stop[nidx] == 1 && seen(nidx)) {
         if (soft) ng += P.obstacle_penalty_stop;
         else continue;
       }

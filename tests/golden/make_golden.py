@@ -77,6 +77,8 @@ SCENARIOS = {
     "despawn_96_s25": dict(size=96, seed=25, vehicles=260, ticks=140,
                            defaults={**CLOSED, "VEHICLE_STUCK_DESPAWN_ENABLED": True, "VEHICLE_STUCK_DESPAWN_THRESHOLD": 14,
                                      "VEHICLE_STUCK_DESPAWN_THRESHOLD_INTERSECTION": 4}),
+    # VEHICLE_RESPECT_AWARENESS: every search of the replanning policy masks obstacles outside the field of view
+    "fov_96_s26": dict(size=96, seed=26, vehicles=220, ticks=100, defaults={**CLOSED, "VEHICLE_RESPECT_AWARENESS": True}),
     # config-5 style: sub-block roads + L-shaped carves
     "carve_96_s10": dict(size=96, seed=10, vehicles=200, ticks=60,
                          defaults={**CLOSED}, model_kwargs=dict(carve_subblock_roads=True)),
@@ -592,6 +594,74 @@ def run_astar_kats():
     np.savez_compressed(os.path.join(HERE, "astar_kats.npz"), **out)
 
 
+def run_astar_fov_kats():
+    """A* with respect_awareness=True (field-of-view masking, astar_numba.py:29-50): the worlds and dynamic state of
+    run_astar_kats (same seeds), awareness ranges 10 and 3, all four (soft, ignore_flow) modes."""
+    import numpy as np
+    _setup_paths()
+    import random
+    from Simulation.config import Defaults
+    Defaults.SAVE_TOTAL_RESULTS = False
+    Defaults.SAVE_INDIVIDUAL_RESULTS = False
+    for k, v in CLOSED.items():
+        setattr(Defaults, k, v)
+    from Simulation.city_model import CityModel
+    from Simulation.utilities.pathfinding.astar_numba import astar_numba
+    out = {}
+    for tag, size, seed, kw in (("a", 64, 21, {}), ("b", 80, 22, dict(carve_subblock_roads=True))):
+        random.seed(seed)
+        m = CityModel(width=size, height=size, seed=seed, **kw)
+        prng = random.Random(seed * 7)
+        road = [(x, y) for y in range(size) for x in range(size) if m.is_road_map[y, x] == 1]
+        for (x, y) in prng.sample(road, len(road) // 8):
+            m.occupancy_map[y, x] = 1
+        for tl in m.traffic_lights:
+            if prng.random() < 0.5:
+                tl.set_light_stop()
+        m._update_density_map()
+        dens64 = m.density_map.astype(np.float64)
+        queries, paths, poff = [], [], [0]
+        nq = 240
+        differs = 0
+        for q in range(nq):
+            (sx, sy), (gx, gy) = prng.choice(road), prng.choice(road)
+            mode = q % 4
+            soft, ign = bool(mode & 1), bool(mode & 2)
+            aw = 10 if (q // 4) % 2 == 0 else 3
+            maxs = 0x7FFFFFFF
+            if ign:
+                maxs = prng.choice([6, 20, 0x7FFFFFFF])
+                if maxs != 0x7FFFFFFF:
+                    cands = [(x, y) for (x, y) in road if 0 < abs(x - sx) + abs(y - sy) <= 8]
+                    if cands:
+                        gx, gy = prng.choice(cands)
+            # the density window follows the same Defaults.VEHICLE_AWARENESS_RANGE a live run passes as awareness_range
+            Defaults.VEHICLE_AWARENESS_RANGE = aw
+            m._update_density_map()
+            dens64 = m.density_map.astype(np.float64)
+            args = (size, size, sx, sy, gx, gy, m.occupancy_map, m.stop_map, m.is_road_map, m.road_type_map, m.allowed_dirs_map)
+            p = astar_numba(*args, respect_awareness=True, awareness_range=aw, density_map=dens64, soft_obstacles=soft,
+                            ignore_flow=ign, maximum_steps=maxs)
+            p0 = astar_numba(*args, respect_awareness=False, awareness_range=aw, density_map=dens64, soft_obstacles=soft,
+                             ignore_flow=ign, maximum_steps=maxs)
+            differs += [tuple(c) for c in p] != [tuple(c) for c in p0]
+            queries.append([sx, sy, gx, gy, int(soft), int(ign), maxs, aw])
+            for c in p:
+                paths.append((int(c[0]), int(c[1])))
+            poff.append(len(paths))
+        wt = world_tables(m)
+        for k in ("allowed_dirs_map", "is_road_map", "road_type_map", "intersection_map"):
+            out[f"{tag}_{k}"] = wt[k]
+        out[f"{tag}_occupancy_map"] = m.occupancy_map.copy()
+        out[f"{tag}_stop_map"] = m.stop_map.copy()
+        out[f"{tag}_queries"] = np.asarray(queries, dtype=np.int64)
+        out[f"{tag}_path_off"] = np.asarray(poff, dtype=np.int32)
+        out[f"{tag}_path_xy"] = np.asarray(paths, dtype=np.int32).reshape(-1, 2)
+        nonempty = sum(1 for i in range(nq) if poff[i + 1] > poff[i])
+        print(f"[astar_fov_kats/{tag}] {nq} queries, {nonempty} non-empty, {differs} differ from the unmasked search")
+    np.savez_compressed(os.path.join(HERE, "astar_fov_kats.npz"), **out)
+
+
 def run_density():
     import numpy as np
     from scipy.ndimage import uniform_filter
@@ -704,7 +774,7 @@ def run_worlds():
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "all":
-        jobs = ["mt", "density", "astar_kats", "worlds"] + list(SCENARIOS)
+        jobs = ["mt", "density", "astar_kats", "astar_fov_kats", "worlds"] + list(SCENARIOS)
         for j in jobs:
             subprocess.run([sys.executable, os.path.abspath(__file__), j], check=True, cwd="/tmp")
         return
@@ -714,6 +784,8 @@ def main():
         run_density()
     elif what == "astar_kats":
         run_astar_kats()
+    elif what == "astar_fov_kats":
+        run_astar_fov_kats()
     elif what == "worlds":
         run_worlds()
     else:

@@ -52,6 +52,14 @@ def test_hip_astar_kats(hip, golden_dir, tag):
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_astar_fov_kats(golden_dir, tag):
+    """ts_astar with VEHICLE_RESPECT_AWARENESS (field-of-view masking) against the reference's astar_numba."""
+    from tests.test_oracle_kats import run_astar_fov_kats
+    from trafficsimulation_amd._lib import new_engine
+    run_astar_fov_kats(new_engine, golden_dir, tag)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
 def test_hip_pathfinder_operator_signature(golden_dir, tag):
     """trafficsimulation_amd.pathfinding.astar_hip - the reference's `astar(...)` operator signature
     (astar_numba.py:243-256) - bound to the HIP library (its default engine factory), on the reference's A* KATs."""
@@ -69,9 +77,9 @@ def test_hip_pathfinder_operator_signature(golden_dir, tag):
             j = 3 * i
             assert got == [tuple(p) for p in xy[off[j]:off[j + 1]].tolist()], f"query {j}: {q[j]}"
         assert len(pathfinding._cache) == 1
-        with pytest.raises(capi.EngineError):
-            pathfinding.astar_hip(W, H, 1, 1, 2, 2, respect_awareness=True, awareness_range=10, density_map=None,
-                                  soft_obstacles=False, ignore_flow=False, **maps)
+        pathfinding.astar_hip(W, H, 1, 1, 2, 2, respect_awareness=True, awareness_range=10, density_map=None,
+                              soft_obstacles=False, ignore_flow=False, **maps)
+        assert len(pathfinding._cache) == 2          # field-of-view masking is an engine parameter: its own instance
     finally:
         pathfinding.release()
 

@@ -69,6 +69,37 @@ def test_astar_kats(oracle, golden_dir, tag):
     assert nonempty > 50
 
 
+def run_astar_fov_kats(make_api, golden_dir, tag):
+    """respect_awareness=True (field-of-view masking, astar_numba.py:29-50) against the reference: 240 queries per map,
+    awareness ranges 10 and 3 (an engine per range: the range is an engine parameter)."""
+    k = np.load(os.path.join(golden_dir, "astar_fov_kats.npz"))
+    q, off, xy = k[f"{tag}_queries"], k[f"{tag}_path_off"], k[f"{tag}_path_xy"]
+    nonempty = 0
+    for aw in sorted(set(int(a) for a in q[:, 7])):
+        api = make_api()
+        p = api.default_params()
+        p.respect_awareness = 1
+        p.vehicle_awareness_range = aw
+        api.create(k[f"{tag}_allowed_dirs_map"], k[f"{tag}_is_road_map"], k[f"{tag}_road_type_map"], k[f"{tag}_intersection_map"], p)
+        api.debug_set_occupancy(k[f"{tag}_occupancy_map"])
+        api.upload_map(capi.MAP_STOP, k[f"{tag}_stop_map"])
+        for i, (sx, sy, gx, gy, soft, ign, maxs, a) in enumerate(q):
+            if int(a) != aw:
+                continue
+            got = api.astar(int(sx), int(sy), int(gx), int(gy), bool(soft), bool(ign), int(maxs))
+            want = xy[off[i]:off[i + 1]]
+            assert np.array_equal(got, want), f"query {i}: {q[i]}"
+            nonempty += len(want) > 0
+        api.close()
+    assert nonempty > 100
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_astar_fov_kats(golden_dir, tag):
+    from oracle import pyoracle
+    run_astar_fov_kats(pyoracle.load, golden_dir, tag)
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_pathfinder_operator_signature(golden_dir, tag):
     """trafficsimulation_amd.pathfinding.astar_hip - the reference's `astar(...)` operator signature - on the A* KATs, here
@@ -88,8 +119,8 @@ def test_pathfinder_operator_signature(golden_dir, tag):
             j = 3 * i
             assert got == [tuple(p) for p in xy[off[j]:off[j + 1]].tolist()], f"query {j}: {q[j]}"
         assert len(pathfinding._cache) == 1          # one engine per set of static maps, reused across calls
-        with pytest.raises(capi.EngineError):
-            pathfinding.astar_hip(W, H, 1, 1, 2, 2, respect_awareness=True, awareness_range=10, density_map=None,
-                                  soft_obstacles=False, ignore_flow=False, _engine_factory=pyoracle.load, **maps)
+        pathfinding.astar_hip(W, H, 1, 1, 2, 2, respect_awareness=True, awareness_range=10, density_map=None,
+                              soft_obstacles=False, ignore_flow=False, _engine_factory=pyoracle.load, **maps)
+        assert len(pathfinding._cache) == 2          # field-of-view masking is an engine parameter: its own instance
     finally:
         pathfinding.release()

@@ -61,7 +61,7 @@ class TsParams(C.Structure):
         ("rain_occurrences_max", C.c_int32), ("rain_cooldown", C.c_int32), ("rain_spawn_offset", C.c_int32),
         ("rain_spawn_chance", C.c_double),
         ("stuck_despawn_enabled", C.c_int32), ("stuck_despawn_threshold", C.c_int32),
-        ("stuck_despawn_threshold_intersection", C.c_int32), ("_pad1", C.c_int32),
+        ("stuck_despawn_threshold_intersection", C.c_int32), ("respect_awareness", C.c_int32),
     ]
 
 
@@ -172,11 +172,11 @@ DEFAULTS_TO_PARAMS = {
     "RAIN_SPAWN_OFFSET": "rain_spawn_offset", "RAIN_SPAWN_CHANCE": "rain_spawn_chance",
     "VEHICLE_STUCK_DESPAWN_ENABLED": "stuck_despawn_enabled", "VEHICLE_STUCK_DESPAWN_THRESHOLD": "stuck_despawn_threshold",
     "VEHICLE_STUCK_DESPAWN_THRESHOLD_INTERSECTION": "stuck_despawn_threshold_intersection",
+    "VEHICLE_RESPECT_AWARENESS": "respect_awareness",
 }
 # switches whose non-default value selects a code path this build does not carry: (unsupported value, why).
 # params_from_defaults refuses them loudly instead of running the default behaviour.
 UNSUPPORTED_DEFAULTS = {
-    "VEHICLE_RESPECT_AWARENESS": (True, "field-of-view masking in A* (astar_numba.py:29-50) is not carried"),
     "PATHFINDING_BATCHING": (False, "the non-batched step path (vehicle_base.py:666-685) is not carried"),
 }
 

@@ -26,6 +26,7 @@
 // runs in k_decide_main (one vehicle per lane, no scratch: bails out as soon as a search is needed) and in
 // k_replan (one vehicle per wave, every lane executing the same code on the same values).
 #pragma once
+#include <type_traits>
 #include "dev.h"
 
 namespace {
@@ -175,9 +176,11 @@ struct ACtx {
   gu64p gq, tab;
   gi8p gd;
   const TS_GLOBAL u64* amap;
+  const TS_GLOBAL u64* fovrun;
   const TS_GLOBAL float* density;
   gi32p outg;
-  int heap_cap, out_cap, start_idx, goal_idx, gx, gy, maximum_steps;
+  int heap_cap, out_cap, start_idx, goal_idx, gx, gy, maximum_steps, sx, sy, aw;
+  bool fov;
   uint32_t epoch;
   bool soft, ignore_flow, limited, turn_on, rt_on, dens_on;
   double turn_pen, contra_pen, veh_pen, stop_pen, dyn_scale, rt1, rt2, rt3;
@@ -217,7 +220,7 @@ enum { AL_EMPTY = -2, AL_OVERFLOW = -1, AL_SWITCH = -3 };   // astar_loop result
 // SPILL = false runs while the whole heap fits LDS (straight LDS accesses); SPILL = true is the general form.  Either
 // returns AL_SWITCH when the other one should take over.
 // ---------------------------------------------------------------------------------------------
-template <bool SPILL, bool HALF>
+template <bool SPILL, bool HALF, bool FOV>
 __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
   // A lone wave issues one instruction every four cycles whatever its kind, so this loop is written for instruction
   // count: lane-parallel vector work and one ballot in place of scalar walks, no scalar <-> vector round trips that
@@ -265,6 +268,8 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     // records of those nodes
     const u64 am_l = C.amap[t_l];
     const float dens_l = C.density[nidx_l];      // (read whether or not the search is soft: no branch around a load)
+    u64 fr_l = 0;
+    if constexpr (FOV) fr_l = C.fovrun[t_l];
     u64 e_l = 0;
     bool e_loaded = false;
     KP(1);
@@ -355,7 +360,18 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     {
       const uint32_t m_l = (uint32_t)(e_l >> 32);
       const int dist_l = (m_l >> T_STAMP_SHIFT) == epoch ? (int)(uint32_t)e_l : A_INF;
-      const bool n_occ = ((a_l >> 8) & 1u) != 0u, n_stop = ((a_l >> 9) & 1u) != 0u, n_road = ((a_l >> 4) & 1u) != 0u;
+      bool n_occ = ((a_l >> 8) & 1u) != 0u, n_stop = ((a_l >> 9) & 1u) != 0u;
+      const bool n_road = ((a_l >> 4) & 1u) != 0u;
+      if constexpr (FOV) {
+        // compute_fov_inplace (astar_numba.py:29-50): the neighbour is seen iff a straight run of road cells joins it to
+        // the line of 2 * awareness - 1 cells through the START cell perpendicular to that run's direction
+        const int dxs = nx_l - C.sx, dys = ny_l - C.sy, aw = C.aw;
+        const int run_dn = (int)(fr_l & 0xFFFF), run_up = (int)((fr_l >> 16) & 0xFFFF), run_lf = (int)((fr_l >> 32) & 0xFFFF), run_rt = (int)(fr_l >> 48);
+        const bool band_x = (dxs < aw) & (dxs > -aw), band_y = (dys < aw) & (dys > -aw);
+        const bool seen = (band_x & (dys >= 0) & (run_dn > dys)) | (band_x & (dys <= 0) & (run_up > -dys)) |
+                          (band_y & (dxs >= 0) & (run_lf > dxs)) | (band_y & (dxs <= 0) & (run_rt > -dxs));
+        n_occ &= seen; n_stop &= seen;
+      }
       const uint32_t rt = (a_l >> 6) & 3u;
       const bool flow = ((bits >> dd_l) & 1u) != 0u;
       const bool turn = C.turn_on & (prev_dir != -1) & (dd_l != prev_dir);
@@ -444,6 +460,9 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   C.gd = (gi8p)(uintptr_t)uni64((u64)(uintptr_t)S.gd);
   C.tab = (gu64p)(uintptr_t)uni64((u64)(uintptr_t)S.tab);
   C.amap = (const TS_GLOBAL u64*)(uintptr_t)uni64((u64)(uintptr_t)d.amap);
+  C.fovrun = (const TS_GLOBAL u64*)(uintptr_t)uni64((u64)(uintptr_t)d.fovrun);
+  C.fov = P.respect_awareness != 0 && d.fovrun != nullptr;
+  C.aw = uni(P.vehicle_awareness_range);
   C.density = (const TS_GLOBAL float*)(uintptr_t)uni64((u64)(uintptr_t)d.density);
   C.outg = (gi32p)(uintptr_t)uni64((u64)(uintptr_t)out);
   C.heap_cap = uni(S.heap_cap);
@@ -468,9 +487,9 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   // the chain of relaxations behind a heap entry never revisits a cell (dist strictly falls), so it is shorter than
   // N: a limit of N or more never binds and the steps need not be carried
   C.limited = C.maximum_steps < C.N;
-  int sx, sy;
   C.xy_of(C.goal_idx, C.gx, C.gy);
-  C.xy_of(C.start_idx, sx, sy);
+  C.xy_of(C.start_idx, C.sx, C.sy);
+  const int sx = C.sx, sy = C.sy;
   if (C.lane == 0) {
     const uint32_t sr = (uint32_t)(C.amap[C.tile_ix(sx, sy)] >> 32);
     if (sr != 0xFFFFFFFFu) C.tab[sr] = (u64)0u | ((u64)(C.epoch << T_STAMP_SHIFT) << 32);    // dist 0, steps 0
@@ -480,21 +499,19 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   int heap_size = 1;
   wave_mem_sync();
   int r;
-  if (C.half) {
+  // (the default policy is the <HALF, no FOV> pair; the other instantiations serve fractional penalties and
+  // VEHICLE_RESPECT_AWARENESS)
+  auto run = [&](auto half_c, auto fov_c) {
+    constexpr bool HF = decltype(half_c)::value, FV = decltype(fov_c)::value;
     for (;;) {
-      r = astar_loop<false, true>(C, heap_size);
-      if (r != AL_SWITCH) break;
-      r = astar_loop<true, true>(C, heap_size);
-      if (r != AL_SWITCH) break;
+      int q = astar_loop<false, HF, FV>(C, heap_size);
+      if (q != AL_SWITCH) return q;
+      q = astar_loop<true, HF, FV>(C, heap_size);
+      if (q != AL_SWITCH) return q;
     }
-  } else {
-    for (;;) {
-      r = astar_loop<false, false>(C, heap_size);
-      if (r != AL_SWITCH) break;
-      r = astar_loop<true, false>(C, heap_size);
-      if (r != AL_SWITCH) break;
-    }
-  }
+  };
+  if (!C.fov) r = C.half ? run(std::true_type{}, std::false_type{}) : run(std::false_type{}, std::false_type{});
+  else r = C.half ? run(std::true_type{}, std::true_type{}) : run(std::false_type{}, std::true_type{});
   S.expansions += C.n_exp; S.relaxations += C.n_relax;
   if (C.lane == 0) {   // profiling aid: deepest heap / longest search any searcher has seen (ts_debug_read words 4, 5)
     atomicMax(&d.cnt->dbg[4], C.max_heap);

@@ -99,6 +99,9 @@ struct Dev {
   // tiled order: a searcher's dist / came_from table has one record per NODE, a quarter of one record per cell.
   unsigned long long* amap;
   int n_nodes;
+  // VEHICLE_RESPECT_AWARENESS only: per cell (tiled order) the lengths of the straight runs of road cells that end in it,
+  // four 16-bit counts (going -y, +y, -x, +x, the cell included): what the field-of-view rays of astar_numba.py:29-50 ask
+  const unsigned long long* fovrun;
   float* density;    // _update_density_map (city_model.py:1764-1778), materialised on demand
   int8_t* occ_snap;  // occupancy at the last tick start (what density_map is a function of)
   // ordered lists

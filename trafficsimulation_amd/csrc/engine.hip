@@ -826,6 +826,32 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
     if (hipMalloc((void**)&t_node, N * 4) != hipSuccess) { (void)hipFree(t_allowed); (void)hipFree(t_road_type); (void)hipFree(t_inter); return bail(TS_E_DEVICE); }
     ok &= hipMemcpy(t_node, node.data(), N * 4, hipMemcpyHostToDevice) == hipSuccess;
   }
+  if (params->respect_awareness) {
+    // straight runs of road cells ending in each cell, for the field-of-view test of the searches (Dev::fovrun)
+    const int W = e->W, H = e->H;
+    std::vector<uint16_t> run((size_t)N * 4, 0);
+    auto road = [&](int x, int y) { return w->is_road_map[(size_t)y * W + x] == 1; };
+    for (int x = 0; x < W; x++) {
+      for (int y = 0; y < H; y++) run[((size_t)y * W + x) * 4 + 0] = road(x, y) ? (uint16_t)std::min(65535, (y > 0 ? run[((size_t)(y - 1) * W + x) * 4 + 0] : 0) + 1) : 0;
+      for (int y = H - 1; y >= 0; y--) run[((size_t)y * W + x) * 4 + 1] = road(x, y) ? (uint16_t)std::min(65535, (y + 1 < H ? run[((size_t)(y + 1) * W + x) * 4 + 1] : 0) + 1) : 0;
+    }
+    for (int y = 0; y < H; y++) {
+      for (int x = 0; x < W; x++) run[((size_t)y * W + x) * 4 + 2] = road(x, y) ? (uint16_t)std::min(65535, (x > 0 ? run[((size_t)y * W + x - 1) * 4 + 2] : 0) + 1) : 0;
+      for (int x = W - 1; x >= 0; x--) run[((size_t)y * W + x) * 4 + 3] = road(x, y) ? (uint16_t)std::min(65535, (x + 1 < W ? run[((size_t)y * W + x + 1) * 4 + 3] : 0) + 1) : 0;
+    }
+    const size_t nt = (size_t)d.W8 * d.H8 * 64;
+    std::vector<unsigned long long> tiled(nt, 0ull);
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        const size_t t = ((((size_t)(y >> 3) * d.W8 + (size_t)(x >> 3)) << 6) | (size_t)((y & 7) << 3) | (size_t)(x & 7));
+        const uint16_t* r = &run[((size_t)y * W + x) * 4];
+        tiled[t] = (unsigned long long)r[0] | ((unsigned long long)r[1] << 16) | ((unsigned long long)r[2] << 32) | ((unsigned long long)r[3] << 48);
+      }
+    unsigned long long* fr = nullptr;
+    ok &= dalloc(e, &fr, nt) == hipSuccess;
+    if (fr) ok &= hipMemcpy(fr, tiled.data(), nt * 8, hipMemcpyHostToDevice) == hipSuccess;
+    d.fovrun = fr;
+  }
   hipLaunchKernelGGL(k_cells_init, dim3(nblk((long long)N)), dim3(BLK), 0, st, d.cell, (int)N, t_allowed, d.is_road, t_road_type, t_inter, t_node);
   uint32_t table[256];
   for (uint32_t i = 0; i < 256; i++) {

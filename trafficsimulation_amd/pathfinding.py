@@ -14,7 +14,8 @@ Differences a caller can observe:
     (`_update_density_map`, bit-exact).  That equals the array the reference passes whenever its density is current,
     i.e. everywhere inside the decide phase; a search started mid-move with a stale `density_map` (soft mode only)
     would see the fresh one here.
-  * `respect_awareness=True` (field-of-view masking, off by default: config.py:278) is refused, not approximated.
+  * `respect_awareness=True` (field-of-view masking, off by default: config.py:278) is carried: the engine for that flag
+    is created with `TsParams.respect_awareness`, `awareness_range` being its `vehicle_awareness_range`.
   * the library must be present: there is no CPU fall-back.
 """
 from __future__ import annotations
@@ -28,8 +29,9 @@ from . import _capi as capi
 _cache: dict = {}     # (W, H, id(is_road), id(road_type), id(allowed)) -> (engine, the three arrays, awareness_range)
 
 
-def _engine_for(width, height, is_road_map, road_type_map, allowed_dirs_map, awareness_range, factory: Optional[Callable]):
-    key = (int(width), int(height), id(is_road_map), id(road_type_map), id(allowed_dirs_map), int(awareness_range))
+def _engine_for(width, height, is_road_map, road_type_map, allowed_dirs_map, awareness_range, factory: Optional[Callable],
+                respect_awareness: bool = False):
+    key = (int(width), int(height), id(is_road_map), id(road_type_map), id(allowed_dirs_map), int(awareness_range), bool(respect_awareness))
     hit = _cache.get(key)
     # the arrays are kept alive by the cache entry, so an equal id() means the very same objects
     if hit is not None and hit[1] is is_road_map and hit[2] is road_type_map and hit[3] is allowed_dirs_map:
@@ -39,7 +41,8 @@ def _engine_for(width, height, is_road_map, road_type_map, allowed_dirs_map, awa
         factory = new_engine          # raises when the HIP library is missing
     api = factory()
     p = api.default_params()
-    p.vehicle_awareness_range = int(awareness_range)      # window of the density map (config.py:279)
+    p.vehicle_awareness_range = int(awareness_range)      # window of the density map (config.py:279) and of the field of view
+    p.respect_awareness = 1 if respect_awareness else 0
     a = np.asarray(allowed_dirs_map)
     if a.shape != (height, width):
         raise ValueError(f"maps must be (height, width) = ({height}, {width}) arrays, got {a.shape}")
@@ -55,9 +58,7 @@ def astar_hip(width: int, height: int, start_x: int, start_y: int, goal_x: int, 
               maximum_steps: int = 0x7FFFFFFF, _engine_factory: Optional[Callable] = None) -> List[Tuple[int, int]]:
     """astar_numba(width, height, sx, sy, gx, gy, occupancy_map, stop_map, is_road_map, road_type_map,
     allowed_dirs_map, respect_awareness, awareness_range, density_map, soft_obstacles, ignore_flow, maximum_steps)."""
-    if respect_awareness:
-        raise capi.EngineError(capi.TS_E_UNSUPPORTED, "respect_awareness=True (field-of-view masking) is not carried")
-    api = _engine_for(width, height, is_road_map, road_type_map, allowed_dirs_map, awareness_range, _engine_factory)
+    api = _engine_for(width, height, is_road_map, road_type_map, allowed_dirs_map, awareness_range, _engine_factory, respect_awareness)
     api.debug_set_occupancy(occupancy_map)          # the dynamic planes as the caller sees them right now
     api.upload_map(capi.MAP_STOP, stop_map)
     xy = api.astar(int(start_x), int(start_y), int(goal_x), int(goal_y), bool(soft_obstacles), bool(ignore_flow),
