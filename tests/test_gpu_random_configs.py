@@ -1,6 +1,7 @@
 """Randomised differential test: HIP engine vs CPU oracle on small synthetic worlds with parameter sets drawn at
 random (light algorithms, speed ranges with power-of-two and non-power-of-two spans, awareness range, replanning
-thresholds, contraflow switches, stranding chances, penalties, rain with a manager, transition timers).  Every
+thresholds, contraflow switches, stranding chances, penalties, rain with a manager, transition timers, stuck despawn,
+field-of-view masking, fractional road-type penalties).  Every
 tick is compared state for state; the draws are seeded, so a failure names its case."""
 import os
 
@@ -45,6 +46,14 @@ def random_case(case: int):
         "TRAFFIC_LIGHT_GREEN_DURATION": int(rng.integers(4, 30)),
         "RAIN_ENABLED": bool(rng.integers(2)),
         "RAIN_RADIUS_MIN": 6, "RAIN_RADIUS_MAX": 20, "RAIN_SPAWN_CHANCE": 0.3, "RAIN_SPEED_REDUCTION": int(rng.integers(1, 4)),
+        # round 2: _despawn_check, field-of-view masking, and penalties that are not multiples of 0.5 (the A*'s double path
+        # instead of its integer half-unit path)
+        "VEHICLE_STUCK_DESPAWN_ENABLED": bool(rng.integers(4) == 0),
+        "VEHICLE_STUCK_DESPAWN_THRESHOLD": int(rng.choice([6, 20, 3600])),
+        "VEHICLE_STUCK_DESPAWN_THRESHOLD_INTERSECTION": int(rng.choice([2, 20])),
+        "VEHICLE_RESPECT_AWARENESS": bool(rng.integers(4) == 0),
+        "VEHICLE_ROAD_TYPES_PENALTY_R2": float(rng.choice([5.0, 5.25, 7.5])),
+        "VEHICLE_TURN_PENALTY": int(rng.choice([10, 3])),
     }
     vehicles = int(rng.integers(40, 700))
     with_manager = d["RAIN_ENABLED"]
