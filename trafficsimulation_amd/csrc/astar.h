@@ -32,26 +32,21 @@
 namespace {
 
 constexpr int A_INF = 0x3F3F3F3F;
-#ifdef TS_KDEBUG
-#define KDBG(...) do { } while (0)
-#define KMARK(k, v) do { if (lane_id() == 0 && blockIdx.x < 8) d.hdbg[blockIdx.x * 8 + (k)] = (v); } while (0)
-#else
-#define KMARK(k, v) do { } while (0)
-#define KDBG(...) do { } while (0)
-#endif
 constexpr int MAXB = 64;  // longest contraflow bypass (VEHICLE_MAX_CONTRAFLOW_*_STEPS <= 64)
 enum { DV_DONE = 0, DV_DEFER = 1, DV_OVERFLOW = 2, DV_POOL_FULL = 3 };
 
+// heap slots (and dir bytes) a searcher keeps in LDS: 9.2 KB, sixteen searchers per CU (the deepest heap seen on
+// 1024^2 - 4096^2 runs is ~1500 entries; what does not fit spills to the searcher's HBM scratch)
 #ifndef TS_LDS_HEAP
 #define TS_LDS_HEAP 1024
 #endif
 constexpr int LDS_HEAP = TS_LDS_HEAP;
-// register budget of the replanning kernel and the functions it calls: at least this many waves per SIMD
+// register budget of the replanning kernels and (propagated by the compiler) of the functions they call: at least this
+// many waves per SIMD - four searchers per SIMD keep its vector ALU ~70 % busy (profiles/r02_sq_replan_2048.json)
 #ifndef TS_REPLAN_WAVES
 #define TS_REPLAN_WAVES 4
 #endif
-#define TS_REPLAN_OCC __attribute__((amdgpu_waves_per_eu(TS_REPLAN_WAVES, 8)))            // heap slots (and dir bytes) a searcher keeps in LDS: 18 KB, eight searchers per CU
-                                          // (two per SIMD; the deepest heap seen on 1024^2 / 2048^2 runs is ~1500 entries)
+#define TS_REPLAN_OCC __attribute__((amdgpu_waves_per_eu(TS_REPLAN_WAVES, 8)))
 struct __attribute__((aligned(8))) HQ { int32_t f, i; };             // heap entry: f_arr, i_arr (g_arr / s_arr: see above)
 struct __attribute__((aligned(8))) TEnt { int32_t dist; uint32_t meta; };   // meta = stamp << 14 | steps << 2 | came-from direction
 constexpr uint32_t T_STAMP_SHIFT = 14, T_STEPS_MASK = 0xFFF, T_STAMP_MAX = (1u << 18) - 1;
@@ -66,7 +61,7 @@ struct AScratch {
   HQ* gq;        // heap slots [LDS_HEAP, heap_cap), indexed by slot - LDS_HEAP
   int8_t* gd;    // dir_arr for the same slots: indexed by heap SLOT and deliberately not moved by the sift routines
   int heap_cap;
-  TEnt* tab;     // W8 * H8 * 64 records, tiled order
+  TEnt* tab;     // one record per search node (Dev::n_nodes), nodes numbered in tiled order
   uint32_t epoch;
   int32_t *A, *P, *T, *PO, *PD;  // cap cells each: A* result, current new path, splice target, staged pre-paths
   int32_t *BYP, *OV, *DV;        // MAXB cells each: bypass result, staged overtake / detour paths

@@ -135,7 +135,6 @@ struct Dev {
   uint32_t* words;      // ring mirror of the global MT19937 stream (tempered words), index = absolute & WORDS_MASK
   uint32_t *Cx, *rollrank, *rollD, *Tcum;
   DevCnt* cnt;
-  volatile int* hdbg;   // debugging aid: progress markers in pinned host memory (TS_KDEBUG builds)
 };
 
 __device__ __forceinline__ int path_dir(const uint32_t* pool, uint32_t off, int k) {

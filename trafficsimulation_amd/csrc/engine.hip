@@ -64,19 +64,6 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     LAUNCH(e, PK_REPLAN, n, k_replan, dim3(grid), dim3(64), d, P, e->slots, rl, e->replan_list[4], e->dist_rank, e->dist_world,
            e->dist_world > 1 ? e->owned_list : nullptr);
     const double tl = now_ms();
-    if (getenv("TS_DEBUG_POLL") && d.hdbg) {   // watch the kernel: after 8 s without completion print the progress markers and stop
-      const double t0 = now_ms();
-      while (hipStreamQuery(st) == hipErrorNotReady) {
-        std::this_thread::sleep_for(std::chrono::milliseconds(50));
-        if (now_ms() - t0 > 8000.0) {
-          for (int b = 0; b < 8; b++)
-            fprintf(stderr, "[poll] wg %d: at=%d j=%d i=%d r=%d iter=%d heap=%d start=%d goal=%d\n", b, d.hdbg[b * 8], d.hdbg[b * 8 + 1], d.hdbg[b * 8 + 2],
-                    d.hdbg[b * 8 + 3], d.hdbg[b * 8 + 4], d.hdbg[b * 8 + 5], d.hdbg[b * 8 + 6], d.hdbg[b * 8 + 7]);
-          fflush(stderr);
-          _exit(3);
-        }
-      }
-    }
     HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
     HIPOK(hipMemcpyAsync(e->hint + 3, &d.cnt->error, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
@@ -862,7 +849,6 @@ int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
   ok &= hipMemcpyAsync(e->d_crc, table, sizeof(table), hipMemcpyHostToDevice, st) == hipSuccess;
   ok &= hipHostMalloc((void**)&e->hcnt, sizeof(DevCnt)) == hipSuccess;
   ok &= hipHostMalloc((void**)&e->hint, sizeof(int) * 16) == hipSuccess;
-  { int* hd = nullptr; ok &= hipHostMalloc((void**)&hd, sizeof(int) * 64) == hipSuccess; if (hd) memset(hd, 0, sizeof(int) * 64); d.hdbg = hd; }
   ok &= hipStreamSynchronize(st) == hipSuccess;
   (void)hipFree(t_allowed); (void)hipFree(t_road_type); (void)hipFree(t_inter); (void)hipFree(t_node);
   if (!ok) return bail(TS_E_DEVICE);

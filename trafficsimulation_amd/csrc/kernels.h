@@ -28,7 +28,8 @@ __global__ void k_decide_pre(Dev d, TsParams P, int start, int n_active) {
       int pos = d.pos[vid];
       int dir = d.dir[vid];
       if (P.sideswipe_active && dir >= 0) {
-        int x = pos % W, y = pos / W;
+        int x, y;
+        cell_xy(d, pos, x, y);
         const int opposite = (dir + 2) & 3;
         for (int k = 0; k < 2 && cand < 0; k++) {
           int ld = k == 0 ? ((dir + 3) & 3) : ((dir + 1) & 3);  // left, then right
