@@ -45,6 +45,16 @@ def main():
                 w.writerow([r[0], r[1], r[2], round(r[3], 3), round(100.0 * r[2] / total, 4), r[4], r[5]])
         for r in rows[:8]:
             print(f"{short(r[0]):24s} calls {r[1]:5d} avg {r[3] / 1e3:9.2f} us  total {r[2] / 1e6:8.2f} ms")
+        # "k_name:N first_leg_calls": the bench line's HIP-event figure covers the timed region only - the last N of the
+        # kernel's launches in the first (headline) leg of the traced process; the trace also holds its warm-up launches
+        for spec in sys.argv[4:]:
+            kname, n = spec.split(":")
+            durs = [r[0] for r in c.execute("select duration from kernels where name like ? order by start", (f"%{kname}%",)).fetchall()]
+            last = durs[-int(n):]
+            with open(sys.argv[3], "a", newline="") as f:
+                csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerow(
+                    [f"{kname} [last {len(last)} launches = the timed region]", len(last), sum(last), round(sum(last) / max(len(last), 1), 3), "", min(last), max(last)])
+            print(f"{kname}: last {len(last)} launches avg {sum(last) / max(len(last), 1) / 1e3:.2f} us")
         return
     f, w = agg(sys.argv[2], "FETCH_SIZE"), agg(sys.argv[3], "WRITE_SIZE")
     out = {}
