@@ -230,6 +230,15 @@ def test_hip_vs_oracle_full_policy_1024():
     assert ch.astar_calls > 1_000 and ch.astar_expansions > 5_000_000
 
 
+def test_hip_vs_oracle_replanning_wave_with_a_full_path_pool(monkeypatch):
+    """The same wave with (almost) no room reserved in the path pool: planners find it full, their entries go to the retry
+    list, the host garbage-collects / grows the pool and the searches run again - state for state against the oracle."""
+    monkeypatch.setenv("TS_DEBUG_POOL_PER_ENTRY", "2")
+    h, c = _pair_full(512, 12_000, 9)
+    ch = _compare_full(h, c, 8)
+    assert ch.astar_calls > 5_000
+
+
 def test_hip_vs_oracle_full_policy_768_through_a_replanning_wave():
     """The same wave one size up (768 x 768 / 30 000 vehicles: tens of thousands of searches of ~10^4 expansions in one
     tick), compared after every second tick."""

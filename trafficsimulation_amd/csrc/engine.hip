@@ -56,8 +56,13 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   if (!e->density_valid) { rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
   // room in the path pool for what these replans will write (a planner that finds the pool full throws its searches
   // away and is run again): 128 words = 2048 path cells per entry, garbage-collecting / growing the pool if need be
-  rc = pool_make_room(e, (size_t)replan_pending(e->hint + 8) * 128 + (1u << 20));
+  // (TS_DEBUG_POOL_PER_ENTRY shrinks the reservation so that tests can walk the pool-full retry path)
+  const char* dbg_per = getenv("TS_DEBUG_POOL_PER_ENTRY");
+  const size_t per_entry = dbg_per ? (size_t)atoi(dbg_per) : 128;
+  rc = pool_make_room(e, (size_t)replan_pending(e->hint + 8) * per_entry + (dbg_per ? 64u : (1u << 20)));
   if (rc) return rc;
+  if (dbg_per) d.pool_cap_words = std::min(e->pool_cap, e->pool_used + (size_t)replan_pending(e->hint + 8) * per_entry + 64u);
+  if (dbg_per && getenv("TS_DEBUG_REPLAN")) fprintf(stderr, "[replan] pool used %zu cap %zu -> logical cap %llu\n", e->pool_used, e->pool_cap, d.pool_cap_words);
   while (replan_pending(e->hint + 8) > 0) {
     const int n = replan_pending(e->hint + 8);
     const int grid = std::min(n, e->slots.n_slots);
@@ -79,6 +84,7 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
               n, e->hint[8], e->hint[9], e->hint[10], e->hint[11], grid, retry, now_ms() - tl);
     if (retry == 0) break;
     // the path pool filled up: make room (GC, then growth) and run the entries that could not commit again
+    d.pool_cap_words = e->pool_cap;
     rc = pool_make_room(e, (size_t)retry * 1024 + (1u << 20));
     if (rc) return rc;
     HIPOK(hipMemcpyAsync(e->replan_list[0], e->replan_list[4], (size_t)retry * 4, hipMemcpyDeviceToDevice, st));
@@ -87,6 +93,7 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     e->hint[8] = retry; e->hint[8 + 6] = keep_owned;
     HIPOK(hipMemcpyAsync(d.cnt->replan_n, e->hint + 8, sizeof(int) * 8, hipMemcpyHostToDevice, st));
   }
+  d.pool_cap_words = e->pool_cap;
   return TS_OK;
 }
 
