@@ -46,7 +46,7 @@ d.destroy_process_group()
 def test_two_ranks_sharded_replans_match_the_reference():
     # closed populations, then the agents that step on the host inside the shuffled order (traffic generator spawning and
     # planning mid-tick, service vehicles with their arrival records, rain): every rank runs those redundantly
-    traces = ["full_64_s1", "full_96_s8", "faults_64_s9", "carve_96_s10", "dta_64_s12", "rain_96_s14", "config1_64_s11", "despawn_96_s25"]
+    traces = ["full_64_s1", "full_96_s8", "faults_64_s9", "carve_96_s10", "dta_64_s12", "rain_96_s14", "config1_64_s11", "despawn_96_s25", "startgoal_96_s27"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
         f.write(WORKER % dict(root=ROOT, traces=traces))

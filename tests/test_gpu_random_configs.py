@@ -67,16 +67,32 @@ def run_case(case, make_engines, ticks=45):
         kinds = list(np.asarray(tb["schedule_kinds0"]))
         tb["schedule_kinds0"] = np.asarray(kinds[:-1] + [2] + kinds[-1:], dtype=np.int8)
     s, g, off, dirs = citygen.make_routes(tb, vehicles, seed=seed + 1, min_len=10, max_len=90)
+    # trips that end where they start (they despawn inside the decide phase and the next vehicle of the decide order loses
+    # its turn): some among the self-planning half, some with an (empty) route of their own on cells that other vehicles
+    # occupy too, some added in the middle of the run; a separate stream so that the other draws of a case stay what they were
+    rng2 = np.random.default_rng(5000 + case)
+    n_sg = int(rng2.choice([0, 0, 1, 3, 8]))
+    h = len(s) // 2
+    g = np.array(g, copy=True)
+    for i in rng2.integers(h, len(s), size=n_sg):
+        g[i] = s[i]
+    sg_cells = np.asarray(s)[rng2.integers(0, len(s), size=n_sg)].reshape(-1, 2)
+    late_cells = np.asarray(s)[rng2.integers(0, len(s), size=n_sg)].reshape(-1, 2)
     apis = make_engines()
     for e in apis:
         build_engine(e, tb, defaults=d, global_seed=seed, sched_seed=seed + 7)
         # half the vehicles bring their route, the other half plan it themselves (spawn-time planner, path cache)
-        h = len(s) // 2
         e.add_vehicles_dirs(s[:h], g[:h], np.full(h, capi.POP["through"], np.int32), off[:h + 1], dirs[:off[h]])
         e.add_vehicles(s[h:], g[h:], np.full(len(s) - h, capi.POP["internal"], np.int32))
+        if n_sg:
+            e.add_vehicles_dirs(sg_cells, sg_cells, np.full(n_sg, capi.POP["through"], np.int32), np.zeros(n_sg + 1, np.int64),
+                                np.zeros(0, np.uint8))
     a, b = apis
     ctx0 = f"case {case} ({size}x{size}, {len(s)} vehicles, {d['TRAFFIC_LIGHT_AGENT_ALGORITHM']})"
     for t in range(ticks):
+        if n_sg and t == 12:
+            for e in apis:
+                e.add_vehicles(late_cells, late_cells, np.full(n_sg, capi.POP["internal"], np.int32))
         a.step(1), b.step(1)
         ctx = f"{ctx0} tick {t}"
         va, vb = a.vehicles(), b.vehicles()

@@ -25,9 +25,11 @@ DTA_TRACES = ["dta_64_s12", "dta_96_s13"]
 RAIN_TRACES = ["rain_96_s14"]
 SERVICE_TRACES = ["service_64_s15", "service_heavy_96_s16", "config1_64_s11", "config5_96_s17"]
 RECT_TRACES = ["rect_96x64_s18", "rect_64x112_s19"]   # non-square grids, every subsystem on
-# constructor variants under a live run; captured after this round's GPU budget was spent, so far replayed on the oracle only
+# constructor variants under a live run
 VARIANT_TRACES = ["unopt_96_s21", "ring_r1_112_s22", "noring_96_s23", "fwdrange_96_s24"]
-DESPAWN_TRACES = ["despawn_96_s25", "fov_96_s26"]      # + VEHICLE_RESPECT_AWARENESS: field-of-view masking in every search                    # VEHICLE_STUCK_DESPAWN_ENABLED with low thresholds: _despawn_check fires
+# VEHICLE_STUCK_DESPAWN_ENABLED with low thresholds (_despawn_check fires); VEHICLE_RESPECT_AWARENESS (field-of-view masking
+# in every search); trips that end where they start (despawn inside the decide phase, the next vehicle's decide is skipped)
+DESPAWN_TRACES = ["despawn_96_s25", "fov_96_s26", "startgoal_96_s27"]
 DEFAULT_TRACES = ["default_200_s20"]                   # CityModel() as the reference ships: 200 x 200, config.py untouched
 
 

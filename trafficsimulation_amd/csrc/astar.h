@@ -1009,7 +1009,11 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
   d.cur_speed[vid] = (int8_t)v.cur;
   d.flags[vid] = early ? (v.f | VF_EARLY) : v.f;
   if (arrived && one) {
-    if (!(v.f & VF_KEEP)) atomicExch(&d.cnt->error, TS_E_UNSUPPORTED);  // despawn inside decide (start == goal)
+    if (!(v.f & VF_KEEP)) {   // a trip that ends where it starts: _despawn inside step_decide.  The host ends the stretch of
+      // the decide order at such a vehicle and takes it off the maps once everybody before it is through (tick())
+      if (d.dec_expect == i + 1) atomicExch(&d.cnt->dec_arrived, i + 1);
+      else atomicExch(&d.cnt->error, TS_E_DEVICE);
+    }
     else if (v.f & VF_TOBLOCK) svc_record(d, i, vid, AR_DECIDE);        // ServiceVehicleAgent._start_service
     else {   // base on_target_reached of a vehicle that stays: trip statistics once more, then _park()
       if (P.enable_traffic && d.pop[vid] == TS_POP_THROUGH) {
@@ -1028,8 +1032,8 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
 }
 
 // every live vehicle: the part of step_decide that needs no search; the others go to the replan list
-__global__ void k_decide_main(Dev d, TsParams P, int n_active, RLists lists) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_decide_main(Dev d, TsParams P, int lo, int n_active, RLists lists) {
+  int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_active) return;
   if (d.cnt->rng_event != 0xFFFFFFFFu) return;  // a malfunction / sideswipe fired: the host re-runs this after the fix-up
   if (decide_vehicle<false>(d, P, i, nullptr) == DV_DEFER) {

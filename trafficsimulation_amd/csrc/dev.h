@@ -43,7 +43,7 @@ struct DevCnt {
   int pend_n[2];   // lengths of the two ping-pong lists of still-unresolved schedule slots
   unsigned int rng_event;   // first (vehicle index * 2 + is_collision) whose draw fired this pass, 0xFFFFFFFF = none
   unsigned int rng_tot[2];  // pass 1 totals: fixed words, number of speed rolls
-  int pad_;
+  int dec_arrived; // 1 + decide index of the vehicle that despawned inside this stretch of the decide phase (0 = none)
   long long prof[8];   // TS_KPROF builds: cycles per segment of the last search's loop
   int dbg[8];      // debugging aid: first watchdog that fired inside a replanning kernel (code, vehicle index, values)
 };
@@ -69,6 +69,7 @@ struct Dev {
   int W8, H8;                   // the map in 8 x 8 tiles (tiled order of the A* snapshot and tables, see tix)
   unsigned long long w_magic;   // floor(2^40 / W) + 1: y = (cell * w_magic) >> 40 is exact for cell < 2^26, W < 2^14
   double elapsed;   // DynamicTrafficAgent.elapsed as the decide phase sees it (before the clock agent steps)
+  int dec_expect;   // 1 + decide index of the one vehicle that may despawn inside this stretch of the decide phase (0 = none)
   Cell* cell;
   // dense byte planes kept next to the records: occ and stop are written through (light groups sum lanes of
   // occupancy, the density map and the host read whole planes), rain is only ever read at a vehicle's own cell

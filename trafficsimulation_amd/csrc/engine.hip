@@ -138,6 +138,7 @@ int exchange_replans(E* e, const DevCnt& before) {
                           after.dist_internal - before.dist_internal, after.dist_through - before.dist_through,
                           after.astar_calls - before.astar_calls, after.astar_exp - before.astar_exp, after.astar_relax - before.astar_relax};
   for (size_t q = 0; q < sizeof(dl) / sizeof(dl[0]); q++) hd.delta[q] = dl[q];
+  hd.delta[13] = after.dec_arrived;
   hd.ddelta[0] = after.dur_internal - before.dur_internal; hd.ddelta[1] = after.dur_through - before.dur_through;
   const size_t bytes = sizeof(XHeader) + (size_t)n_owned * sizeof(ReplanRec) + (size_t)n_words * 4 + (size_t)std::max(n_arr, 0) * 12;
   e->send_buf.resize(bytes);
@@ -182,6 +183,7 @@ int exchange_replans(E* e, const DevCnt& before) {
     merged.astar_calls += h2.delta[10]; merged.astar_exp += h2.delta[11]; merged.astar_relax += h2.delta[12];
     merged.dur_internal += h2.ddelta[0]; merged.dur_through += h2.ddelta[1];
     if (h2.error && !merged.error) merged.error = (int)h2.error;
+    if ((int)h2.delta[13] > merged.dec_arrived) merged.dec_arrived = (int)h2.delta[13];
     if (h2.n_recs > 0) {
       if ((size_t)h2.n_recs > e->cap_recs) { const size_t nc = (size_t)h2.n_recs * 2; int rc = regrow(e, &e->d_recs, 0, nc); if (rc) return rc; e->cap_recs = nc; }
       if ((size_t)h2.n_words + 16 > e->cap_xwords) { const size_t nc = (size_t)h2.n_words * 2 + 4096; int rc = regrow(e, &e->d_xwords, 0, nc); if (rc) return rc; e->cap_xwords = nc; }
@@ -234,10 +236,28 @@ int tick(E* e) {
   Dev& d = e->d;
   const TsParams& P = e->P;
   hipStream_t st = e->stream;
-  const int nA = e->n_active, nS = e->n_sched;
-  // the scheduler stream is independent of everything the decide phase does: shuffle on a host thread
-  shuffle_start(e, nS);
+  int nA = e->n_active, nS = e->n_sched;
+  // Vehicles that stand on their target (a trip that ends where it starts) despawn inside the decide phase
+  // (vehicle_base.py:657-661) - and leave the schedule before it is shuffled.  `standing` = their decide indices.
+  std::vector<int32_t> standing;
+  if (e->standing_possible && nA > 0) {
+    if (!e->d_standing) HIPOK(dalloc(e, &e->d_standing, (size_t)E::STANDING_CAP + 1));
+    HIPOK(hipMemsetAsync(e->d_standing, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_find_standing, dim3(nblk(nA)), dim3(BLK), 0, st, d, nA, e->d_standing, (int)E::STANDING_CAP);
+    int32_t n_st = 0;
+    HIPOK(hipMemcpyAsync(&n_st, e->d_standing, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    if (n_st > E::STANDING_CAP) return fail(e, TS_E_CAPACITY, "more than 4096 vehicles stand on their own target");
+    standing.resize((size_t)n_st);
+    if (n_st > 0) HIPOK(hipMemcpy(standing.data(), e->d_standing + 1, (size_t)n_st * 4, hipMemcpyDeviceToHost));
+    std::sort(standing.begin(), standing.end());
+    if (n_st == 0) e->standing_possible = false;
+  }
+  const bool careful = !standing.empty();
+  // the scheduler stream is independent of everything the decide phase does: shuffle on a host thread (unless the decide
+  // phase may still change the schedule)
   struct Joiner { E* e; bool done = false; ~Joiner() { if (!done) shuffle_wait(e); } } joiner{e};
+  if (!careful) shuffle_start(e, nS); else joiner.done = true;
   const double t_tick0 = now_ms();
 
   // density_map is a function of the occupancy at this point (city_model.py:1853)
@@ -263,6 +283,9 @@ int tick(E* e) {
   // ---------------- decide ----------------
   if (nA > 0) {
     HIPOK(hipMemsetAsync(d.ev, 0, (size_t)e->n_vehicles_total, st));
+    // One stretch [lo, hi) of the decide order, start to finish: draws, step_decide, the searches it asks for.  A tick
+    // is one stretch unless a vehicle may despawn inside the decide phase (see below).
+    auto decide_range = [&](const int lo, const int hi) -> int {
     HIPOK(hipMemsetAsync(d.cnt->replan_n, 0, sizeof(int) * 8, st));
     // random() < c  <=>  the 53-bit integer (a << 26 | b) < ceil(c * 2^53)   (exact: power-of-two scaling)
     auto thr53 = [](double c) -> unsigned long long {
@@ -279,11 +302,11 @@ int tick(E* e) {
     // vehicles per pass (bounds the look-ahead into the word ring); TS_DEBUG_SEG shrinks it so that tests can walk
     // the multi-pass path on small worlds
     static const int SEG = getenv("TS_DEBUG_SEG") ? std::max(64, atoi(getenv("TS_DEBUG_SEG"))) : (1 << 20);
-    int start = 0;
+    int start = lo;
     bool main_done = false;
-    LAUNCH(e, PK_DECIDE_PRE, nA, k_decide_pre, dim3(nblk(nA)), dim3(BLK), d, P, 0, nA);
-    while (start < nA) {
-      const int seg_end = std::min(nA, start + SEG), n = seg_end - start;
+    LAUNCH(e, PK_DECIDE_PRE, hi - lo, k_decide_pre, dim3(nblk(hi - lo)), dim3(BLK), d, P, lo, hi);
+    while (start < hi) {
+      const int seg_end = std::min(hi, start + SEG), n = seg_end - start;
       const int nb = nblk(n, BLK * RS_ITEMS);
       // pass 1 (device): fixed-word prefix sums, roll ranks, roll start offsets
       HIPOK(hipMemsetAsync(&d.cnt->rng_event, 0xFF, sizeof(unsigned int), st));
@@ -396,8 +419,8 @@ int tick(E* e) {
                              T_swipe, span, rshift, P.vehicle_min_speed);
           prof_end(e, tok);
         }
-        if (seg_end == nA) {  // k_decide_main returns at once if a draw fired (the fix-up below re-runs it)
-          LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, rlists);
+        if (seg_end == hi) {  // k_decide_main returns at once if a draw fired (the fix-up below re-runs it)
+          LAUNCH(e, PK_DECIDE_MAIN, hi - lo, k_decide_main, dim3(nblk(hi - lo)), dim3(BLK), d, P, lo, hi, rlists);
           HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
         }
         HIPOK(hipMemcpyAsync(e->hint + 6, &d.cnt->rng_event, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
@@ -408,7 +431,7 @@ int tick(E* e) {
         if (evk == 0xFFFFFFFFu) {
           r.advance_to(final_pos);
           start = seg_end;
-          main_done = seg_end == nA;
+          main_done = seg_end == hi;
           continue;
         }
         // rare: a malfunction / sideswipe fired at vehicle ev_at.  Everything before it stands; apply the event,
@@ -427,15 +450,16 @@ int tick(E* e) {
         r.advance_to(after);
         LAUNCH(e, PK_EVENT, 1, k_apply_event, dim3(1), dim3(64), d, P, e->hint[0], ev_coll, e->hint[1], ev_at);
         start = ev_at + 1;
-        if (start < nA) LAUNCH(e, PK_DECIDE_PRE, nA - start, k_decide_pre, dim3(nblk(nA - start)), dim3(BLK), d, P, start, nA);
+        if (start < hi) LAUNCH(e, PK_DECIDE_PRE, hi - start, k_decide_pre, dim3(nblk(hi - start)), dim3(BLK), d, P, start, hi);
       }
     }
     if (!main_done) {  // the last pass ended with an event at the very last vehicle (or there was no pass left)
       HIPOK(hipMemsetAsync(&d.cnt->rng_event, 0xFF, sizeof(unsigned int), st));
-      LAUNCH(e, PK_DECIDE_MAIN, nA, k_decide_main, dim3(nblk(nA)), dim3(BLK), d, P, nA, rlists);
+      LAUNCH(e, PK_DECIDE_MAIN, hi - lo, k_decide_main, dim3(nblk(hi - lo)), dim3(BLK), d, P, lo, hi, rlists);
       HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
       HIPOK(hipStreamSynchronize(st));
     }
+    if (hi == nA) {
     // prefetch the part of the stream the next tick will most likely read
     { const double t_wu = now_ms(); int rc = words_upload(e, r.pos() + (uint64_t)nA * 4 + (1u << 16)); if (rc) return rc;
       host_prof(e, PH_WORDS, now_ms() - t_wu, nA); }
@@ -456,6 +480,7 @@ int tick(E* e) {
         e->take_base = nb; e->take_n = nt;
       }
     }
+    }
     if (e->dist_world > 1) {
       // every rank sees the same work lists (as sets): plan this rank's share, then trade results - also when this
       // rank has nothing to plan, the exchange is collective
@@ -468,6 +493,54 @@ int tick(E* e) {
       int rc = exchange_replans(e, before);
       if (rc) return rc;
     } else if (replan_pending(e->hint + 8) > 0) { int rc = run_replans(e); if (rc) return rc; }
+    return TS_OK;
+    };
+    if (!careful) {
+      int rc = decide_range(0, nA);
+      if (rc) return rc;
+    } else {
+      // Stretch by stretch, each ending at a vehicle that may despawn: everybody up to and including it decides (draws,
+      // searches and all), then it leaves the maps and the vehicle behind it loses its turn (k_decide_despawn) - the
+      // later stretches see exactly what the reference's sequential loop would show them.
+      int lo = 0, removed = 0;
+      size_t ci = 0;
+      while (lo < nA) {
+        while (ci < standing.size() && standing[ci] < lo) ci++;   // (it was the one that lost its turn)
+        const bool at_candidate = ci < standing.size();
+        const int hi = at_candidate ? standing[ci] + 1 : nA;
+        d.dec_expect = at_candidate ? hi : 0;
+        if (at_candidate) HIPOK(hipMemsetAsync(&d.cnt->dec_arrived, 0, sizeof(int), st));
+        int rc = decide_range(lo, hi);
+        d.dec_expect = 0;
+        if (rc) return rc;
+        lo = hi;
+        if (at_candidate) {
+          int arrived = 0;
+          HIPOK(hipMemcpyAsync(&arrived, &d.cnt->dec_arrived, sizeof(int), hipMemcpyDeviceToHost, st));
+          HIPOK(hipStreamSynchronize(st));
+          if (arrived == hi) {
+            hipLaunchKernelGGL(k_decide_despawn, dim3(1), dim3(64), 0, st, d, P, hi - 1, hi < nA ? hi : -1);
+            e->amap_valid = false;
+            removed++;
+            lo = hi + 1;
+          }
+          ci++;
+        }
+      }
+      if (removed > 0) {   // the schedule is shuffled without them (RandomActivation.step takes the live keys)
+        int na = 0, ns = 0;
+        int rc = compact(e, 0, e->n_active, &na); if (rc) return rc;
+        rc = compact(e, 1, e->n_sched, &ns); if (rc) return rc;
+        e->n_active = na; e->n_sched = ns; e->n_sched_vehicles -= removed;
+        nA = na; nS = ns;
+        if (e->clock_slot >= 0 && e->mixed_order) {
+          std::vector<int8_t> kinds(ns);
+          HIPOK(hipMemcpy(kinds.data(), d.sched_kind, ns, hipMemcpyDeviceToHost));
+          e->clock_slot = -1;
+          for (int q = 0; q < ns; q++) if (kinds[q] == TS_AGENT_CLOCK) { e->clock_slot = q; break; }
+        }
+      }
+    }
     if (svc_on) {
       // on_target_reached inside step_decide for vehicles that stay on the grid (vehicle_base.py:657-661): apply the
       // flag changes now that no decider can see them half-way, then the host part in decide order
@@ -486,6 +559,7 @@ int tick(E* e) {
     }
   }
 
+  if (careful) { shuffle_start(e, nS); joiner.done = false; }
   // ---------------- move (schedule.step) ----------------
   const double t_dec1 = now_ms();
   host_prof(e, PH_DECIDE_WALL, t_dec1 - t_tick0, nA);
@@ -681,7 +755,7 @@ int tick(E* e) {
       }
       e->hint[3] = dev_error; e->hint[1] = dev_deaths;
     }
-    if (e->hint[3]) return fail(e, e->hint[3], "device-side error: a vehicle sits on its target during decide (start == goal is not supported)");
+    if (e->hint[3]) return fail(e, e->hint[3], "device-side error: a vehicle despawned inside the decide phase without the host expecting it (internal error)");
     if (discs.n >= 0)   // RainManager.step ran: rain_map is exactly the union of the discs it saw
     {
       hipLaunchKernelGGL(k_rain_map, dim3(nblk((long long)e->N)), dim3(BLK), 0, st, d.rain, e->W, e->H, e->prev_discs, discs);
@@ -1220,6 +1294,7 @@ static int add_vehicles_core(ts_handle e, int n, std::vector<int32_t>& start, st
 // VehicleAgent.__init__ for one vehicle whose path the engine plans itself: place_vehicle, then
 // self.path = self._compute_path() with city._path_cache (vehicle_base.py:78-81, 143-167)
 static int add_vehicle_planned(ts_handle e, int start, int goal, int pop_type) {
+  if (start == goal) e->standing_possible = true;   // it despawns inside the next decide phase (tick())
   std::vector<int32_t> s1{start}, g1{goal}, p1{pop_type}, l1{0};
   std::vector<uint32_t> o1{0}, enc;
   int rc = add_vehicles_core(e, 1, s1, g1, p1, l1, o1, enc);
@@ -1293,7 +1368,7 @@ static int add_vehicles_any(ts_handle e, int32_t n, const int32_t* start_xy, con
       int sx = start_xy[2 * i], sy = start_xy[2 * i + 1], gx = goal_xy[2 * i], gy = goal_xy[2 * i + 1];
       if (sx < 0 || sx >= W || sy < 0 || sy >= H || gx < 0 || gx >= W || gy < 0 || gy >= H)
         return fail(e, TS_E_INVALID, "vehicle start/goal out of bounds");
-      if (sx == gx && sy == gy) return fail(e, TS_E_UNSUPPORTED, "start == goal (vehicle despawns inside the decide phase)");
+      if (sx == gx && sy == gy) e->standing_possible = true;   // it despawns inside the next decide phase (tick())
       if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
       int rc = add_vehicle_planned(e, sy * W + sx, gy * W + gx, population_type ? population_type[i] : TS_POP_UNDEFINED);
       if (rc) return rc;
@@ -1317,7 +1392,7 @@ static int add_vehicles_any(ts_handle e, int32_t n, const int32_t* start_xy, con
     int sx = start_xy[2 * i], sy = start_xy[2 * i + 1], gx = goal_xy[2 * i], gy = goal_xy[2 * i + 1];
     if (sx < 0 || sx >= W || sy < 0 || sy >= H || gx < 0 || gx >= W || gy < 0 || gy >= H)
       return fail(e, TS_E_INVALID, "vehicle start/goal out of bounds");
-    if (sx == gx && sy == gy) return fail(e, TS_E_UNSUPPORTED, "start == goal (vehicle despawns inside the decide phase)");
+    if (sx == gx && sy == gy) e->standing_possible = true;
     start[i] = sy * W + sx; goal[i] = gy * W + gx;
     pop[i] = population_type ? population_type[i] : TS_POP_UNDEFINED;
     const long long o = O(i);

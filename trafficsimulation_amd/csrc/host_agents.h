@@ -372,7 +372,6 @@ int generator_step(E* e) {
     }
     if (t.kind == TS_POP_INTERNAL) e->C.created_internal++; else e->C.created_through++;
     (void)e->rng_global.randint(0, 9999);  // the id suffix of "V_{depart:06d}_{randint(0, 9999):04d}"
-    if (t.origin == t.dest) return fail(e, TS_E_UNSUPPORTED, "generated trip with origin == destination");
     if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
     int rc = add_vehicle_planned(e, t.origin, t.dest, t.kind);
     if (rc) return rc;

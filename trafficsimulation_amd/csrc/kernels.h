@@ -842,6 +842,39 @@ __global__ void k_decide_arrive(Dev d, int n_rec) {
   if (f & VF_TOBLOCK) f = (f & ~VF_TOBLOCK) | VF_SERVICING;
   d.flags[vid] = f;
 }
+// Vehicles that stand on their target at the start of a tick and are not kept on arrival (a trip that ends where it
+// starts): they despawn inside step_decide (vehicle_base.py:657-661).  list[0] = count, list[1..] = decide indices.
+__global__ void k_find_standing(Dev d, int n_active, int32_t* list, int cap) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_active) return;
+  const int vid = d.active[i];
+  if (vid < 0) return;
+  const uint16_t f = d.flags[vid];
+  if ((f & VF_KEEP) || !(f & VF_ALIVE) || d.pos[vid] != d.target[vid]) return;
+  const int k = atomicAdd(&list[0], 1);
+  if (k < cap) list[1 + k] = i;
+}
+// ... and the despawn itself, run once every vehicle before number i_arrived of the decide order is through with its
+// step_decide (searches included): on_target_reached -> _despawn -> CityModel.remove_vehicle.  The removal happens while
+// run_parallel_decide iterates active_vehicle_agents (city_model.py:1817-1827), so the list iterator skips the vehicle
+// that follows (i_skipped, -1 = none): it does not decide in this tick at all.  Whoever looks at it later in this decide
+// phase must see its stored state - it is marked as "not yet decided" (the compaction that follows every despawn
+// restores active_idx).
+__global__ void k_decide_despawn(Dev d, TsParams P, int i_arrived, int i_skipped) {
+  if (threadIdx.x || blockIdx.x) return;
+  const int vid = d.active[i_arrived];
+  uint16_t f = d.flags[vid];
+  on_target_reached_dev(d, P, vid, d.sched_slot[vid], d.pos[vid], f, d.elapsed, i_arrived);
+  d.flags[vid] = f;
+  if (i_skipped >= 0) {
+    const int w = d.active[i_skipped];
+    if (w >= 0) {
+      const bool sb = (d.flags[w] & (VF_COLL | VF_MALF)) != 0;
+      d.st_before[w] = sb; d.st_after[w] = sb;
+      d.active_idx[w] = 0x7FFFFFFF;
+    }
+  }
+}
 // (schedule slot, rank) of CityBlocks (which = 0, ids = block index) or vehicles (which = 1, ids = vehicle id)
 __global__ void k_gather_ranks(Dev d, const int32_t* ids, int n, int which, int32_t* out) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
