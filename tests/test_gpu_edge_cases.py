@@ -199,7 +199,7 @@ def test_error_codes_match():
         with pytest.raises(capi.EngineError) as ei:
             e.upload_map(capi.MAP_OCCUPANCY, np.zeros(tb["is_road_map"].shape, np.int8))
         assert ei.value.code == capi.TS_E_INVALID
-    with pytest.raises(capi.EngineError) as ei:       # the engine refuses what it cannot reproduce exactly
-        h.add_vehicles([[20, 20]], [[20, 20]], [0], [0, 0], np.zeros((0, 2), np.int32))
-    assert ei.value.code == capi.TS_E_UNSUPPORTED
+    for e in (h, c):       # a trip that ends where it starts is accepted (it despawns inside the next decide phase)
+        e.add_vehicles([[20, 20]], [[20, 20]], [0], [0, 0], np.zeros((0, 2), np.int32))
+        assert e.num_vehicles() == 1
     h.close(), c.close()

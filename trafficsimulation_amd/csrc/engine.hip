@@ -26,6 +26,9 @@
 #include <unordered_map>
 #include <vector>
 #include <unistd.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>   // host_shuffle.h: the AVX-512 draw extraction (picked at run time)
+#endif
 
 #include "../../include/trafficsim.h"
 #include "mt19937.h"
