@@ -67,3 +67,45 @@ def test_two_ranks_sharded_replans_match_the_reference():
         assert a["astar_calls"] == b["astar_calls"]
         assert a["fp"] == b["fp"]
         assert a["exchanges"] == b["exchanges"] > 0 and a["bytes"] > 0 and b["bytes"] > 0   # both ranks planned something
+
+
+NCCL_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+import torch.distributed as dist
+from trafficsimulation_amd import dist as tdist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+sr = tdist.ShardedReplans(device=torch.device("cuda", 0))
+ok = True
+for n in (0, 1, 4097, 3_000_000):
+    payload = np.random.default_rng(n).integers(0, 256, size=n, dtype=np.uint8).tobytes()
+    stacked, sizes = sr.gather_bytes(payload)
+    ok &= sizes == [n] and stacked.shape == (1, max(n, 1)) and stacked[0, :n].tobytes() == payload
+# the ctypes callback the engine calls (ts_exchange_fn), end to end
+import ctypes as C
+buf = (C.c_uint8 * 5)(1, 2, 3, 4, 5)
+recv, sizes_p, stride = C.c_void_p(), C.c_void_p(), C.c_int64()
+rc = sr._callback(None, C.addressof(buf), 5, C.pointer(recv), C.pointer(sizes_p), C.pointer(stride))
+got = C.string_at(recv.value, 5)
+ok &= rc == 0 and got == bytes([1, 2, 3, 4, 5]) and stride.value == 5 and C.cast(sizes_p.value, C.POINTER(C.c_int64))[0] == 5
+print(json.dumps({"ok": bool(ok), "backend": dist.get_backend(), "calls": sr.calls}))
+dist.destroy_process_group()
+'''
+
+
+def test_exchange_collective_over_rccl():
+    """The same exchange object on a real RCCL process group (backend "nccl", buffers staged through the GPU).  One rank
+    only - this box has one GPU and RCCL refuses two ranks on a device - so this checks the device staging, the padded
+    all_gather and the callback plumbing, not the wire."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(NCCL_WORKER % dict(root=ROOT))
+        path = f.name
+    out = subprocess.run([sys.executable, path], env=env, capture_output=True, text=True, timeout=600)
+    os.unlink(path)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    row = json.loads([line for line in out.stdout.splitlines() if line.startswith("{")][-1])
+    assert row["ok"] and row["backend"] == "nccl" and row["calls"] == 5
