@@ -255,6 +255,16 @@ def test_hip_vs_oracle_config3_2048_500k():
     assert ch.astar_calls > 1_000
 
 
+def test_hip_vs_oracle_full_policy_4096_1m_first_ticks():
+    """bench.py's default workload itself - 4096 x 4096, 10^6 vehicles, the reference's default policy - for its first four
+    ticks (the replans start with the third: some 2.5 x 10^4 searches on 4096 searcher slots with 32 MB tables each),
+    state for state after the second and the fourth.  (A
+    replanning wave of this size is hours of oracle time; waves are compared at 512^2 .. 1024^2 above.)"""
+    h, c = _pair_full(4096, 1_000_000, 1)
+    ch = _compare_full(h, c, 4, every=2)
+    assert ch.astar_calls > 5_000
+
+
 def test_hip_vs_oracle_full_size_4096_1m():
     """BASELINE.json's headline size (4096x4096, 10^6 vehicles), 6 ticks, compared state for state."""
     h, c = _pair(4096, 1_000_000, 1, {})
