@@ -165,6 +165,26 @@ __device__ __forceinline__ uint32_t next_epoch(const Dev& d, AScratch& S) {
 }
 
 // what a search keeps in registers while its loop runs (d, P and S themselves live in scratch memory behind references)
+// Half units carry the search costs exactly iff every penalty is a non-negative multiple of 0.5 of moderate size (the
+// reference's defaults are).  Host (k_amap_build's penalty bits) and device (astar_wave) decide with the same function.
+__host__ __device__ inline bool astar_half_units(const TsParams& P) {
+  const double pp[7] = {(double)P.turn_penalty, (double)P.contraflow_penalty, (double)P.obstacle_penalty_vehicle,
+                        (double)P.obstacle_penalty_stop, (double)P.road_type_penalty_r1, (double)P.road_type_penalty_r2,
+                        (double)P.road_type_penalty_r3};
+  bool half = true;
+  for (int k = 0; k < 7; k++) half = half && pp[k] >= 0.0 && pp[k] < 1048576.0 && (double)(int)(pp[k] * 2.0) == pp[k] * 2.0;
+  half = half && P.dynamic_penalty_scale >= 0.0 && P.dynamic_penalty_scale <= 64.0;   // (2 (g + 1) + penalties stays below 2^31 for every g < INF)
+  // the per-cell vehicle penalty travels in 22 bits of the map snapshot (density <= 1)
+  half = half && (double)P.obstacle_penalty_vehicle * (1.0 + (double)P.dynamic_penalty_scale) * 2.0 < 2097152.0;
+  return half;
+}
+// obstacle penalty of an occupied cell under VEHICLE_DYNAMIC_PENALTIES (astar_numba.py:203-206): int(veh_pen * (1 + scale * density))
+__device__ __forceinline__ double occ_penalty_dyn(double veh_pen, double dyn_scale, float dens) {
+#pragma clang fp contract(off)
+  return __builtin_trunc(veh_pen * (1.0 + dyn_scale * (double)dens));
+}
+constexpr int AMAP_PEN_SHIFT = 10;   // Dev::amap low word: bits 0-9 flags, bits 10-31 the vehicle penalty in half units (HALF searches)
+
 struct ACtx {
   int W, H, W8, N, lane;
   u64 w_magic;
@@ -262,7 +282,8 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     // round 1: the map entries (flags + search-node number); round 2, issued half-way through the sift-down: the table
     // records of those nodes
     const u64 am_l = C.amap[t_l];
-    const float dens_l = C.density[nidx_l];      // (read whether or not the search is soft: no branch around a load)
+    float dens_l = 0.0f;      // (HALF searches find the cell's vehicle penalty in the map entry itself)
+    if constexpr (!HALF) dens_l = C.density[nidx_l];      // (read whether or not the search is soft: no branch around a load)
     u64 fr_l = 0;
     if constexpr (FOV) fr_l = C.fovrun[t_l];
     u64 e_l = 0;
@@ -376,8 +397,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
         int n2 = 2 * (g + 1);
         n2 += turn ? C.turn2 : 0;
         n2 += flow ? 0 : C.contra2;
-        const int dyn2 = 2 * (int)__builtin_trunc(C.veh_pen * (1.0 + C.dyn_scale * (double)dens_l));
-        const int occ2 = C.dens_on ? dyn2 : C.veh2;
+        const int occ2 = (int)(a_l >> AMAP_PEN_SHIFT);     // k_amap_build: veh2, or the density-dependent penalty of this cell
         n2 += n_occ ? occ2 : 0;
         n2 += n_stop ? C.stop2 : 0;
         const int rtp = rt == 1u ? C.rt2_1 : rt == 2u ? C.rt2_2 : rt == 3u ? C.rt2_3 : 0;
@@ -388,7 +408,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
         ng_l = (double)(g + 1);
         ng_l += turn ? C.turn_pen : 0.0;
         ng_l += flow ? 0.0 : C.contra_pen;
-        const double occ_pen = C.dens_on ? __builtin_trunc(C.veh_pen * (1.0 + C.dyn_scale * (double)dens_l)) : C.veh_pen;
+        const double occ_pen = C.dens_on ? occ_penalty_dyn(C.veh_pen, C.dyn_scale, dens_l) : C.veh_pen;
         ng_l += n_occ ? occ_pen : 0.0;
         ng_l += n_stop ? C.stop_pen : 0.0;
         ng_l += (C.rt_on & n_road) ? (rt == 1u ? C.rt1 : rt == 2u ? C.rt2 : rt == 3u ? C.rt3 : 0.0) : 0.0;
@@ -468,11 +488,7 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   C.rt2 = P.road_type_penalty_r2; C.rt3 = P.road_type_penalty_r3;
   {
     // half units carry the costs exactly iff every penalty is a non-negative multiple of 0.5 of moderate size
-    const double pp[7] = {C.turn_pen, C.contra_pen, C.veh_pen, C.stop_pen, C.rt1, C.rt2, C.rt3};
-    bool half = true;
-    for (int k = 0; k < 7; k++) half = half && pp[k] >= 0.0 && pp[k] < 1048576.0 && (double)(int)(pp[k] * 2.0) == pp[k] * 2.0;
-    half = half && C.dyn_scale >= 0.0 && C.dyn_scale <= 64.0;   // (2 (g + 1) + penalties stays below 2^31 for every g < INF)
-    C.half = half;
+    C.half = astar_half_units(P);
     C.turn2 = (int)(C.turn_pen * 2.0); C.contra2 = (int)(C.contra_pen * 2.0); C.veh2 = (int)(C.veh_pen * 2.0); C.stop2 = (int)(C.stop_pen * 2.0);
     C.rt2_1 = (int)(C.rt1 * 2.0); C.rt2_2 = (int)(C.rt2 * 2.0); C.rt2_3 = (int)(C.rt3 * 2.0);
   }

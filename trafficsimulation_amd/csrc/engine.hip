@@ -54,9 +54,9 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   for (int q = 0; q < 6; q++) rl.l[q] = e->replan_list[q];
   int rc = ensure_slots(e);
   if (rc) return rc;
+  if (!e->density_valid) { rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
   rc = ensure_amap(e);
   if (rc) return rc;
-  if (!e->density_valid) { rc = ensure_density(e, d.occ_snap); if (rc) return rc; e->density_valid = true; }
   // room in the path pool for what these replans will write (a planner that finds the pool full throws its searches
   // away and is run again): 128 words = 2048 path cells per entry, garbage-collecting / growing the pool if need be
   // (TS_DEBUG_POOL_PER_ENTRY shrinks the reservation so that tests can walk the pool-full retry path)

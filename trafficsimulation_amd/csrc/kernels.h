@@ -806,13 +806,18 @@ __global__ void k_cells_init(Cell* cell, int n, const uint8_t* allowed, const in
   cell[c] = x;
 }
 // the A* snapshot of the maps (Dev::amap) from the cell records
-__global__ void k_amap_build(Dev d) {
+// pen_mode: what the penalty bits carry for searches in half units - 0 nothing (penalties are not multiples of 0.5: those
+// searches read the density map themselves), 1 the constant vehicle penalty, 2 the density-dependent one of this cell
+// (VEHICLE_DYNAMIC_PENALTIES; density = the tick-start snapshot, so a rebuild inside the tick gives the same bits)
+__global__ void k_amap_build(Dev d, int pen_mode, double veh_pen, double dyn_scale) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.N) return;
   int x, y;
   cell_xy(d, c, x, y);
   const uint2 w = *reinterpret_cast<const uint2*>(&d.cell[c].occ);   // .x = occ | stop << 8 | stuck << 16 | stat << 24, .y = node number
-  const uint32_t flags = (w.x >> 24) | (((int8_t)(w.x & 0xFF) == 1) ? 0x100u : 0u) | (((int8_t)((w.x >> 8) & 0xFF) == 1) ? 0x200u : 0u);
+  uint32_t flags = (w.x >> 24) | (((int8_t)(w.x & 0xFF) == 1) ? 0x100u : 0u) | (((int8_t)((w.x >> 8) & 0xFF) == 1) ? 0x200u : 0u);
+  const int pen2 = pen_mode == 0 ? 0 : pen_mode == 1 ? (int)(veh_pen * 2.0) : 2 * (int)occ_penalty_dyn(veh_pen, dyn_scale, d.density[c]);
+  flags |= (uint32_t)pen2 << AMAP_PEN_SHIFT;
   d.amap[tix(d, x, y)] = (unsigned long long)flags | ((unsigned long long)w.y << 32);
 }
 __global__ void k_claims_reset(Cell* cell, int n) {
