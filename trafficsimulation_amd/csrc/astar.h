@@ -133,6 +133,15 @@ __device__ __forceinline__ u64 uni64(u64 v) {
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
   return ((u64)hi << 32) | lo;
 }
+// Element `idx` of an array of 8-byte records whose byte size stays below 4 GiB (map snapshot, searcher tables: at most
+// 2^26 records): the 32-bit byte offset lets the access use its scalar-base + 32-bit-offset form instead of 64-bit
+// vector address arithmetic.
+__device__ __forceinline__ u64 ld8(const TS_GLOBAL u64* base, uint32_t idx) {
+  return *(const TS_GLOBAL u64*)((const TS_GLOBAL char*)base + (uint32_t)(idx << 3));
+}
+__device__ __forceinline__ void st8(TS_GLOBAL u64* base, uint32_t idx, u64 v) {
+  *(TS_GLOBAL u64*)((TS_GLOBAL char*)base + (uint32_t)(idx << 3)) = v;
+}
 // heap slot k / its dir byte: LDS below LDS_HEAP, the searcher's HBM spill above (gq / gd are the slot's spill arrays).
 // SPILL = false: the caller guarantees k < LDS_HEAP - straight LDS accesses, no branch (and with it no conservative
 // wait for the expansion's loads in flight) in the hot loop.
@@ -281,11 +290,11 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     const uint32_t t_l = inb_l ? C.tile_ix(nx_l, ny_l) : C.tile_ix(cx, cy);
     // round 1: the map entries (flags + search-node number); round 2, issued half-way through the sift-down: the table
     // records of those nodes
-    const u64 am_l = C.amap[t_l];
+    const u64 am_l = ld8(C.amap, t_l);
     float dens_l = 0.0f;      // (HALF searches find the cell's vehicle penalty in the map entry itself)
     if constexpr (!HALF) dens_l = C.density[nidx_l];      // (read whether or not the search is soft: no branch around a load)
     u64 fr_l = 0;
-    if constexpr (FOV) fr_l = C.fovrun[t_l];
+    if constexpr (FOV) fr_l = ld8(C.fovrun, t_l);
     u64 e_l = 0;
     bool e_loaded = false;
     KP(1);
@@ -317,7 +326,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
         if (done & (lane == 0)) hq_put<SPILL>(gq, abs_end, x);
         if (!e_loaded) {                   // the first window is done: the map entries have had time to arrive
           const uint32_t r_l = (uint32_t)(am_l >> 32);
-          e_l = tab[r_l != 0xFFFFFFFFu ? r_l : 0u];
+          e_l = ld8(tab, r_l != 0xFFFFFFFFu ? r_l : 0u);
           e_loaded = true;
         }
         if (done) break;
@@ -328,7 +337,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     KP(2);
     const uint32_t a_l = (uint32_t)am_l, r_l = (uint32_t)(am_l >> 32);
     const bool node_l = r_l != 0xFFFFFFFFu;
-    if (!e_loaded) e_l = tab[node_l ? r_l : 0u];     // (the heap held a single entry: no sift-down happened)
+    if (!e_loaded) e_l = ld8(tab, node_l ? r_l : 0u);     // (the heap held a single entry: no sift-down happened)
     if (cur == C.goal_idx) {
       // walk came_from back to the start, filling the output from its far end, then slide it to the front
       const gi32p outg = C.outg;
@@ -430,7 +439,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     const int ngi_l = HALF ? (ng2_l >> 1) : (int)ng_l;
     const u64 ent_l = hq_pack(HALF ? ngi_l + h_l : (int)(ng_l + (double)h_l), nidx_l);
     if (ok_l) {
-      tab[r_l] = (u64)(uint32_t)ngi_l | ((u64)(stamp | (C.limited ? (uint32_t)(steps + 1) << 2 : 0u) | (uint32_t)dd_l) << 32);
+      st8(tab, r_l, (u64)(uint32_t)ngi_l | ((u64)(stamp | (C.limited ? (uint32_t)(steps + 1) << 2 : 0u) | (uint32_t)dd_l) << 32));
       hd_put<SPILL>(gd, heap_size + __builtin_popcount(relax & below_l), dd_l);
     }
     KP(5);
