@@ -271,6 +271,22 @@ def test_hip_vs_oracle_full_size_4096_1m():
     _compare(h, c, 6, every=3)
 
 
+@pytest.mark.skipif(not os.environ.get("TS_BIG_TESTS"), reason="BASELINE config 5's size: about five minutes (TS_BIG_TESTS=1)")
+def test_hip_vs_oracle_config5_size_8192_4m():
+    """BASELINE config 5's size on ONE GPU: 8192 x 8192, 4 x 10^6 vehicles + 3.3 x 10^5 QUEUE_ACTUATED light groups (more
+    than 2^22 scheduled agents: 24-bit ranks in the claim words), replans gated off; the decide phase runs in four passes
+    over the MT19937 word ring.  Three ticks, compared state for state after the last."""
+    import bench
+    from oracle import pyoracle
+    from trafficsimulation_amd._lib import new_engine
+    tables, routes, _ = bench.make_workload(8192, 4_000_000, 1)
+    h, c = new_engine(), pyoracle.load()
+    bench.setup(h, tables, routes, 1, policy="lights")
+    bench.setup(c, tables, routes, 1, policy="lights")
+    assert h.num_scheduled() > (1 << 22)
+    _compare(h, c, 3, every=3)
+
+
 def test_facade_on_hip(hip):
     """The Mesa-shaped facade (CityModel / VehicleAgent / grid / schedule) over the HIP engine."""
     from tests.test_mesa_facade import run_facade_against_trace

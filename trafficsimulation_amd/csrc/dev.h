@@ -21,7 +21,7 @@ constexpr int LAST_IDX = 0x7FFFFFFF;  // "decides after everyone": planners that
 constexpr int AR_START = 0 /* _start_service in the move phase, key = rank */, AR_DECIDE = 1 /* on_target_reached inside
                    step_decide, key = decide-order index: applied by k_decide_arrive */, AR_DESPAWN = 2 /* service vehicle left */;
 constexpr int8_t K_VEHICLE = 100, K_DEAD = -1, K_RAIN = 5;  // K_RAIN: a RainAgent's schedule entry
-constexpr uint32_t RANK_BITS = 22, RANK_MASK = (1u << RANK_BITS) - 1, EPOCHS = 1u << (32 - RANK_BITS);
+constexpr uint32_t RANK_BITS = 24, RANK_MASK = (1u << RANK_BITS) - 1, EPOCHS = 1u << (32 - RANK_BITS);
 constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
 
 // decide-phase flag byte F (k_decide_pre -> host scan)

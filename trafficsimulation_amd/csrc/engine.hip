@@ -46,6 +46,8 @@ namespace {
 // lists 0..3 = the classes, list 4 = entries that found the path pool full.
 inline int replan_pending(const int* n8) { return n8[0] + n8[1] + n8[2] + n8[3]; }
 
+constexpr int SEG_VEHICLES = 1 << 20;   // vehicles per decide pass (bounds one pass' look-ahead into the MT19937 word ring)
+
 int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   Dev& d = e->d;
   const TsParams& P = e->P;
@@ -304,7 +306,7 @@ int tick(E* e) {
     for (int q = 0; q < 6; q++) rlists.l[q] = e->replan_list[q];
     // vehicles per pass (bounds the look-ahead into the word ring); TS_DEBUG_SEG shrinks it so that tests can walk
     // the multi-pass path on small worlds
-    static const int SEG = getenv("TS_DEBUG_SEG") ? std::max(64, atoi(getenv("TS_DEBUG_SEG"))) : (1 << 20);
+    static const int SEG = getenv("TS_DEBUG_SEG") ? std::max(64, atoi(getenv("TS_DEBUG_SEG"))) : SEG_VEHICLES;
     int start = lo;
     bool main_done = false;
     LAUNCH(e, PK_DECIDE_PRE, hi - lo, k_decide_pre, dim3(nblk(hi - lo)), dim3(BLK), d, P, lo, hi);
@@ -464,7 +466,10 @@ int tick(E* e) {
     }
     if (hi == nA) {
     // prefetch the part of the stream the next tick will most likely read
-    { const double t_wu = now_ms(); int rc = words_upload(e, r.pos() + (uint64_t)nA * 4 + (1u << 16)); if (rc) return rc;
+    // (at most one pass' worth - the ring holds MAX_AHEAD_BLOCKS blocks; populations above SEG vehicles decide in passes)
+    { const double t_wu = now_ms();
+      const uint64_t ahead = std::min<uint64_t>((uint64_t)std::min(nA, SEG_VEHICLES) * 4 + (1u << 16), MTPipe::MAX_AHEAD_BLOCKS * 600ull - (1u << 16));
+      int rc = words_upload(e, r.pos() + ahead); if (rc) return rc;
       host_prof(e, PH_WORDS, now_ms() - t_wu, nA); }
     {
       // ... and build the next tick's take table behind that upload, on the copy stream: kernel and download
@@ -1372,13 +1377,13 @@ static int add_vehicles_any(ts_handle e, int32_t n, const int32_t* start_xy, con
       if (sx < 0 || sx >= W || sy < 0 || sy >= H || gx < 0 || gx >= W || gy < 0 || gy >= H)
         return fail(e, TS_E_INVALID, "vehicle start/goal out of bounds");
       if (sx == gx && sy == gy) e->standing_possible = true;   // it despawns inside the next decide phase (tick())
-      if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
+      if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^24 agents");
       int rc = add_vehicle_planned(e, sy * W + sx, gy * W + gx, population_type ? population_type[i] : TS_POP_UNDEFINED);
       if (rc) return rc;
     }
     return TS_OK;
   }
-  if ((long long)e->n_sched + n >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
+  if ((long long)e->n_sched + n >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^24 agents");
   std::vector<int32_t> start(n), goal(n), pop(n), plen(n);
   std::vector<uint32_t> poff(n);
   auto O = [&](int i) -> long long { return off32 ? (long long)off32[i] : (long long)off64[i]; };

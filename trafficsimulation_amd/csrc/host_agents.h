@@ -68,7 +68,7 @@ int rain_add_random(E* e) {
   c.dx = dx / l2; c.dy = dy / l2;
   c.radius = r.randint(e->P.rain_radius_min, e->P.rain_radius_max);
   // schedule.add(rain): a new entry at the end of the schedule (it does not step in the tick that created it)
-  if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
+  if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^24 agents");
   int rc = ensure_vehicle_capacity(e, e->cap_v, e->n_sched + 1);
   if (rc) return rc;
   const int hid = e->n_host_agents;
@@ -320,7 +320,7 @@ int spawn_service_at(E* e, int origin, int kind, int id) {
     }
     live = 1;
   }
-  if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
+  if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^24 agents");
   if (!e->d.arr) {   // first service vehicle of this engine: the record buffer the kernels report arrivals in
     e->d.arr_cap = 1 << 16;
     HIPOK(dalloc(e, &e->d.arr, (size_t)e->d.arr_cap * 3));
@@ -372,7 +372,7 @@ int generator_step(E* e) {
     }
     if (t.kind == TS_POP_INTERNAL) e->C.created_internal++; else e->C.created_through++;
     (void)e->rng_global.randint(0, 9999);  // the id suffix of "V_{depart:06d}_{randint(0, 9999):04d}"
-    if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^22 agents");
+    if ((long long)e->n_sched + 1 >= (long long)RANK_MASK) return fail(e, TS_E_CAPACITY, "schedule exceeds 2^24 agents");
     int rc = add_vehicle_planned(e, t.origin, t.dest, t.kind);
     if (rc) return rc;
   }
