@@ -103,6 +103,9 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_wave_barrier(); }
 // values every lane holds alike: tell the compiler (scalar registers, scalar branches) / read one lane's copy
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// __ballot() takes an int: a lane predicate would be turned into 0 / 1 and compared against 0 again (two vector
+// instructions and a hazard nop per ballot); this form hands the compare's own lane mask over
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ double rl(double v, int lane) {
   const long long b = __double_as_longlong(v);
@@ -218,7 +221,8 @@ struct ACtx {
     else { y = cell / W; x = cell - y * W; }
   }
   __device__ __forceinline__ uint32_t tile_ix(int x, int y) const {
-    return ((((uint32_t)(y >> 3) * (uint32_t)W8 + (uint32_t)(x >> 3)) << 6) | (uint32_t)((y & 7) << 3) | (uint32_t)(x & 7));
+    // (tile rows and tiles per row are far below 2^24: the full-rate 24-bit multiply)
+    return (((__umul24((uint32_t)(y >> 3), (uint32_t)W8) + (uint32_t)(x >> 3)) << 6) | (uint32_t)((y & 7) << 3) | (uint32_t)(x & 7));
   }
 };
 #ifdef TS_KPROF
@@ -263,6 +267,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
   const int wadj = (lane & 1) == 0 ? 1 : 0;                       // left children (even lanes) win ties against their sibling
   unsigned long long wanc = 0;                                     // this lane's ancestors-or-self inside the window
   for (int j = 0; j < wlvl; j++) wanc |= 1ull << (lane >> j);
+  if (!wlane) wanc = ~0ull;                                        // lanes 0-1 hold no entry: their path test can never pass (bits 0-1 of a winner mask are never set)
   {  // pin the mask in registers: left alone, the compiler re-derives it (a six-step loop) in every turn of the main loop
     unsigned lo = (unsigned)wanc, hi = (unsigned)(wanc >> 32);
     asm volatile("" : "+v"(lo), "+v"(hi));
@@ -312,12 +317,15 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
         // smallest of (x, left, right) with ties going to x, then left (heap_sift_down, astar_numba.py:67-85):
         // "my entry moves up if my parent is the hole" - at most one of two siblings.  Left: mine <= sibling's, right:
         // mine < sibling's; keys are >= 0, so mine <= s is (mine - 1) < s.
-        const unsigned long long wmask = __ballot((mf < xf) & ((mf - wadj) < sf));
+        // (one compare per ballot: the backend hands a compare's lane mask over as it is, anything else is turned into
+        // 0 / 1 and compared again.)  mf < xf and mf - wadj < sf  <=>  mf < min(xf, sf + wadj), in unsigned arithmetic
+        // (keys are >= 0, an empty slot is 0x7FFFFFFF: the sum cannot wrap)
+        const unsigned long long wmask = ballot((unsigned)mf < min((unsigned)xf, (unsigned)sf + (unsigned)wadj));
         // A lane's entry is on the sift path iff it and all its ancestors inside the window are winners: one mask
         // test per lane (wanc = the lane's ancestors-or-self).  Exactly one lane per level can pass, so a second
         // ballot yields both the number of levels the hole sinks (k) and where it ends up (L).
-        const bool onp = wlane & ((wmask & wanc) == wanc);
-        const unsigned long long pmask = __ballot(onp);
+        const bool onp = (wmask & wanc) == wanc;
+        const unsigned long long pmask = ballot(onp);
         const int k = __builtin_popcountll(pmask);
         const int L = 63 - __builtin_clzll(pmask | 2ull);             // deepest lane on the path; the hole itself (1) if none
         if (onp) hq_put<SPILL>(gq, (abs_l - 1) >> 1, mine);          // the entries on the path move up one level
@@ -428,7 +436,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     // ---- commit.  The four neighbours are distinct cells, so no relaxation changes another one's test: the table
     // records and the dir bytes of all of them go out with one masked store each; only the heap pushes are made one
     // after the other, in the reference's order N, E, S, W.
-    unsigned relax = (unsigned)(__ballot(ok_l) & 15ull);
+    unsigned relax = (unsigned)(ballot(ok_l) & 15ull);
     KP(4);
     if (relax == 0u) continue;
     const int n_new = __builtin_popcount(relax);
@@ -454,7 +462,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
       const bool has = lane < depth;                                  // depth <= 31: lanes beyond it fetch nothing
       const int a_mine = (int)(((unsigned)(i + 1) >> ((lane + 1) & 31)) - 1u) & (has ? -1 : 0);
       const u64 anc = hq_get<SPILL>(gq, a_mine);
-      const unsigned long long rises = __ballot(has & (nf < hq_f(anc)));
+      const unsigned long long rises = ballot(has & (nf < hq_f(anc)));
       const int r = __builtin_ctzll(~rises);                          // leading ancestors the entry passes (lanes >= 31 never rise)
       if (lane < r) hq_put<SPILL>(gq, (int)((unsigned)(i + 1) >> (lane & 31)) - 1, anc);   // ancestor k moves to where k - 1 was
       if (lane == 0) hq_put<SPILL>(gq, ((i + 1) >> r) - 1, nx64);
@@ -1074,6 +1082,18 @@ __global__ void k_decide_main(Dev d, TsParams P, int lo, int n_active, RLists li
     const int h = min(max((int)d.tier_hint[vid], by_dist), 3);
     lists.l[h][atomicAdd(&d.cnt->replan_n[h], 1)] = i;
   }
+}
+
+// sort key of a replanning entry: Morton index of the 32 x 32-cell block its vehicle stands in (run_replans)
+__global__ void k_replan_keys(Dev d, const int32_t* list, int n, uint32_t* keys) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int vid = d.active[list[j]];
+  int x = 0, y = 0;
+  if (vid >= 0) cell_xy(d, d.pos[vid], x, y);
+  uint32_t bx = (uint32_t)x >> 5, by = (uint32_t)y >> 5, k = 0;
+  for (int b = 0; b < 8; b++) k |= ((bx >> b) & 1u) << (2 * b) | ((by >> b) & 1u) << (2 * b + 1);
+  keys[j] = k;
 }
 
 // One turn of a searcher wave at the replanning work queue: take the next entry, run the vehicle's step_decide with
