@@ -35,16 +35,18 @@ constexpr int A_INF = 0x3F3F3F3F;
 constexpr int MAXB = 64;  // longest contraflow bypass (VEHICLE_MAX_CONTRAFLOW_*_STEPS <= 64)
 enum { DV_DONE = 0, DV_DEFER = 1, DV_OVERFLOW = 2, DV_POOL_FULL = 3 };
 
-// heap slots (and dir bytes) a searcher keeps in LDS: 9.2 KB, sixteen searchers per CU (the deepest heap seen on
-// 1024^2 - 4096^2 runs is ~1500 entries; what does not fit spills to the searcher's HBM scratch)
+// heap slots (and dir bytes) a searcher keeps in LDS: 6.2 KB, twenty-four searchers per CU (the deepest heap seen on
+// 1024^2 - 4096^2 runs is ~2100 entries; what does not fit spills to the searcher's HBM scratch)
 #ifndef TS_LDS_HEAP
-#define TS_LDS_HEAP 1024
+#define TS_LDS_HEAP 704
 #endif
 constexpr int LDS_HEAP = TS_LDS_HEAP;
 // register budget of the replanning kernels and (propagated by the compiler) of the functions they call: at least this
-// many waves per SIMD - four searchers per SIMD keep its vector ALU ~70 % busy (profiles/r02_sq_replan_2048.json)
+// many waves per SIMD.  Four searchers per SIMD keep its vector ALU ~70 % busy (profiles/r02_sq_replan_2048.json); six
+// (the search loop needs 72 vector registers then, spills stay outside it) are 11 % faster at 4096^2 / 10^6 vehicles once
+// the queue is ordered in space
 #ifndef TS_REPLAN_WAVES
-#define TS_REPLAN_WAVES 4
+#define TS_REPLAN_WAVES 6
 #endif
 #define TS_REPLAN_OCC __attribute__((amdgpu_waves_per_eu(TS_REPLAN_WAVES, 8)))
 struct __attribute__((aligned(8))) HQ { int32_t f, i; };             // heap entry: f_arr, i_arr (g_arr / s_arr: see above)
