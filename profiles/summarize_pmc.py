@@ -49,7 +49,8 @@ def main():
         # kernel's launches in the first (headline) leg of the traced process; the trace also holds its warm-up launches
         for spec in sys.argv[4:]:
             kname, n = spec.split(":")
-            durs = [r[0] for r in c.execute("select duration from kernels where name like ? order by start", (f"%{kname}%",)).fetchall()]
+            # (exactly this kernel: `k_replan(`, not k_replan_keys / k_replan_export)
+            durs = [r[0] for r in c.execute("select duration from kernels where name like ? order by start", (f"%{kname}(%",)).fetchall()]
             last = durs[-int(n):]
             with open(sys.argv[3], "a", newline="") as f:
                 csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerow(
