@@ -96,9 +96,20 @@ __device__ __forceinline__ void scratch_bind(const ASlots& t, int slot, AScratch
   S.epoch = t.slot_epoch[slot];
   S.calls = 0; S.expansions = 0; S.relaxations = 0;
 }
-// replanning class (work-queue order: largest first) from the expansions the vehicle's last replan took
-__device__ __forceinline__ int cost_class(long long expansions) {
-  return expansions < 2048 ? 0 : expansions < 32768 ? 1 : expansions < 262144 ? 2 : 3;
+// Work-queue order of the replans (largest first).  Per vehicle the bit length of the expansions its last replan took is
+// kept (Dev::tier_hint); the four classes are ranges of it (< 2 048, < 32 768, < 262 144 expansions, more), and inside a
+// class the queue is sorted by it again (run_replans), so that the longest search of a tick starts first.
+__device__ __forceinline__ int cost_bits(long long expansions) {
+  return 64 - __builtin_clzll((unsigned long long)max(expansions, 0ll) | 1ull);
+}
+__device__ __forceinline__ int cost_class_of_bits(int b) { return b < 12 ? 0 : b < 16 ? 1 : b < 19 ? 2 : 3; }
+// ... and for a vehicle without history, from the distance to its target: the searches are Dijkstra-like (the heuristic is
+// far below the penalties), so they touch on the order of md^2 / 2 cells
+__device__ __forceinline__ int cost_bits_of_distance(int md) { return md < 60 ? 8 : md < 240 ? 13 : md < 680 ? 17 : 19; }
+__device__ __forceinline__ int replan_cost_bits(const Dev& d, int vid) {
+  int x0, y0, x1, y1;
+  cell_xy(d, d.pos[vid], x0, y0); cell_xy(d, d.target[vid], x1, y1);
+  return max((int)d.tier_hint[vid], cost_bits_of_distance(abs(x0 - x1) + abs(y0 - y1)));
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -1072,30 +1083,26 @@ __global__ void k_decide_main(Dev d, TsParams P, int lo, int n_active, RLists li
   if (i >= n_active) return;
   if (d.cnt->rng_event != 0xFFFFFFFFu) return;  // a malfunction / sideswipe fired: the host re-runs this after the fix-up
   if (decide_vehicle<false>(d, P, i, nullptr) == DV_DEFER) {
-    // work-queue class (largest first): what the vehicle's last replan cost, or what a search over this distance
-    // is likely to cost - the searches are Dijkstra-like (the heuristic is far below the penalties), so they touch
-    // on the order of md^2 / 2 cells
-    const int vid = d.active[i];
-    const int p0 = d.pos[vid], p1 = d.target[vid];
-    int x0, y0, x1, y1;
-    cell_xy(d, p0, x0, y0); cell_xy(d, p1, x1, y1);
-    const int md = abs(x0 - x1) + abs(y0 - y1);
-    const int by_dist = md < 60 ? 0 : md < 240 ? 1 : md < 680 ? 2 : 3;
-    const int h = min(max((int)d.tier_hint[vid], by_dist), 3);
+    // work-queue class (largest first): what the vehicle's last replan cost, or what a search over this distance is
+    // likely to cost
+    const int h = cost_class_of_bits(replan_cost_bits(d, d.active[i]));
     lists.l[h][atomicAdd(&d.cnt->replan_n[h], 1)] = i;
   }
 }
 
-// sort key of a replanning entry: Morton index of the 32 x 32-cell block its vehicle stands in (run_replans)
+// sort key of a replanning entry (run_replans): expected cost, largest first (bit length of the expansions, see cost_bits),
+// then the Morton index of the 32 x 32-cell block its vehicle stands in
+constexpr int REPLAN_KEY_BITS = 21;
 __global__ void k_replan_keys(Dev d, const int32_t* list, int n, uint32_t* keys) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int vid = d.active[list[j]];
-  int x = 0, y = 0;
-  if (vid >= 0) cell_xy(d, d.pos[vid], x, y);
+  int x = 0, y = 0, bits = 0;
+  if (vid >= 0) { cell_xy(d, d.pos[vid], x, y); bits = min(replan_cost_bits(d, vid), 31); }
   uint32_t bx = (uint32_t)x >> 5, by = (uint32_t)y >> 5, k = 0;
   for (int b = 0; b < 8; b++) k |= ((bx >> b) & 1u) << (2 * b) | ((by >> b) & 1u) << (2 * b + 1);
-  keys[j] = k;
+  // (only the long searches are ordered by cost - 65 536 expansions and more, bit by bit; the bulk stays in plain spatial order)
+  keys[j] = ((uint32_t)(31 - max(bits, 16)) << 16) | k;
 }
 
 // One turn of a searcher wave at the replanning work queue: take the next entry, run the vehicle's step_decide with
@@ -1123,7 +1130,7 @@ __device__ __attribute__((noinline)) int replan_turn(const Dev& d, const TsParam
   if (threadIdx.x == 0) {
     if (r == DV_DONE) {  // work of attempts that are re-run after pool growth is not counted twice
       const int vid = d.active[i];
-      if (S->calls > c0) d.tier_hint[vid] = (uint8_t)cost_class(S->expansions - e0);
+      if (S->calls > c0) d.tier_hint[vid] = (uint8_t)cost_bits(S->expansions - e0);
       atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)(S->calls - c0));
       atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)(S->expansions - e0));
       atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)(S->relaxations - r0));

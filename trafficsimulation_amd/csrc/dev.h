@@ -91,7 +91,7 @@ struct Dev {
   int32_t* ax_start[4];
   uint32_t* ax_off[4];
   int32_t* ax_len[4];
-  uint8_t* tier_hint;  // per vehicle: cost class (0..3) of its last replan, orders the replanning work queue
+  uint8_t* tier_hint;  // per vehicle: bit length of the expansions its last replan took (astar.h: cost_bits), orders the replanning work queue
   uint8_t* chg;        // per vehicle: what its replan of this tick rewrote (bit 0 path, bits 1-4 aux paths) - read and cleared by
                        // k_replan_export in the multi-GPU mode
   // what a search reads about a cell, as of the last tick start (or the last ensure_amap), in tiled order: low word =

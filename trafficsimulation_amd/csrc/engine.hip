@@ -70,13 +70,14 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   if (rc) return rc;
   if (dbg_per) d.pool_cap_words = std::min(e->pool_cap, e->pool_used + (size_t)replan_pending(e->hint + 8) * per_entry + 64u);
   if (dbg_per && getenv("TS_DEBUG_REPLAN")) fprintf(stderr, "[replan] pool used %zu cap %zu -> logical cap %llu\n", e->pool_used, e->pool_cap, d.pool_cap_words);
-  // Order every class list in space (Morton order of 32 x 32-cell blocks of the vehicles' positions): the searches that
-  // run at the same time then read the same few megabytes of the map snapshot, which stay in the XCDs' L2s instead of
-  // competing with 4 096 private tables for the MALL.  The order of the queue does not touch any result.
+  // Order every class list by expected cost (largest first: the longest search of a tick bounds it) and, among equals, in
+  // space (Morton order of 32 x 32-cell blocks of the vehicles' positions): the searches that run at the same time then
+  // read the same few megabytes of the map snapshot, which stay in the XCDs' L2s instead of competing with thousands of
+  // private tables for the MALL.  The order of the queue does not touch any result.
   static const bool spatial = !getenv("TS_NO_SPATIAL_QUEUE");
   for (int h = 0; h < 4 && spatial; h++) {
     const int n = e->hint[8 + h];
-    if (n < 4096) continue;
+    if (n < 256) continue;
     if ((size_t)n > e->cap_sortbuf) {
       const size_t nc = (size_t)n * 2;
       rc = regrow(e, &e->sort_keys, 0, nc); if (rc) return rc;
@@ -86,12 +87,12 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     }
     hipLaunchKernelGGL(k_replan_keys, dim3(nblk(n)), dim3(BLK), 0, st, d, e->replan_list[h], n, e->sort_keys);
     size_t tmp_bytes = 0;
-    HIPOK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, e->sort_keys, e->sort_keys_alt, e->replan_list[h], e->sort_vals_alt, n, 0, 16, st));
+    HIPOK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, e->sort_keys, e->sort_keys_alt, e->replan_list[h], e->sort_vals_alt, n, 0, REPLAN_KEY_BITS, st));
     if (tmp_bytes > e->cap_sorttmp) {
       rc = regrow(e, &e->sort_tmp, 0, tmp_bytes * 2); if (rc) return rc;
       e->cap_sorttmp = tmp_bytes * 2;
     }
-    HIPOK(hipcub::DeviceRadixSort::SortPairs(e->sort_tmp, tmp_bytes, e->sort_keys, e->sort_keys_alt, e->replan_list[h], e->sort_vals_alt, n, 0, 16, st));
+    HIPOK(hipcub::DeviceRadixSort::SortPairs(e->sort_tmp, tmp_bytes, e->sort_keys, e->sort_keys_alt, e->replan_list[h], e->sort_vals_alt, n, 0, REPLAN_KEY_BITS, st));
     HIPOK(hipMemcpyAsync(e->replan_list[h], e->sort_vals_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
   }
   while (replan_pending(e->hint + 8) > 0) {
