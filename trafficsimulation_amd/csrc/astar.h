@@ -293,11 +293,13 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     if (!SPILL && heap_size > LDS_HEAP - 4) return AL_SWITCH;        // this turn's pushes might not fit LDS
     if (SPILL && heap_size < LDS_HEAP / 2) return AL_SWITCH;
     KP(7);
-    const u64 top = g_lq[0];
+    // one LDS read serves the root (lane 0; every lane gets it through readfirstlane) and the first sift-down window
+    // (lanes 2..63: slots 1..62 - the window below a hole at the root): nothing has written to them in this turn yet
+    const u64 w0 = g_lq[max(lane - 1, 0)];
     const int prev_dir = uni((int)g_ld[0]);
     const u64 x = uni64(hq_get<SPILL>(gq, heap_size - 1));            // the last entry: it takes the root's place
     const int xd = uni(hd_get<SPILL>(gd, heap_size - 1));
-    const int f_top = uni(hq_f(top)), cur = uni(hq_i(top));
+    const int f_top = uni(hq_f(w0)), cur = uni(hq_i(w0));     // (readfirstlane: lane 0's word, the root)
     heap_size--;
     KP(0);
     int cx, cy;
@@ -324,7 +326,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
       for (;;) {
         const int abs_l = ((idx + 1) << wlvl) + woff - 1;
         const bool valid = wlane & (abs_l < heap_size);
-        const u64 mine = hq_get<SPILL>(gq, valid ? abs_l : 0);
+        const u64 mine = idx == 0 ? w0 : hq_get<SPILL>(gq, valid ? abs_l : 0);   // (idx == 0: abs_l = lane - 1, read above)
         const int mf = valid ? hq_f(mine) : 0x7FFFFFFF;
         const int sf = __builtin_amdgcn_mov_dpp(mf, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: the sibling's key
         // smallest of (x, left, right) with ties going to x, then left (heap_sift_down, astar_numba.py:67-85):
