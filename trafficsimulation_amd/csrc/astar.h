@@ -35,7 +35,7 @@ constexpr int A_INF = 0x3F3F3F3F;
 constexpr int MAXB = 64;  // longest contraflow bypass (VEHICLE_MAX_CONTRAFLOW_*_STEPS <= 64)
 enum { DV_DONE = 0, DV_DEFER = 1, DV_OVERFLOW = 2, DV_POOL_FULL = 3 };
 
-// heap slots (and dir bytes) a searcher keeps in LDS: 6.2 KB, twenty-four searchers per CU (the deepest heap seen on
+// heap slots (and dir bytes) a searcher keeps in LDS: 6.2 KB, twenty-four searchers per CU (736 entries already cost occupancy) (the deepest heap seen on
 // 1024^2 - 4096^2 runs is ~2100 entries; what does not fit spills to the searcher's HBM scratch)
 #ifndef TS_LDS_HEAP
 #define TS_LDS_HEAP 704
@@ -226,7 +226,7 @@ struct ACtx {
   double turn_pen, contra_pen, veh_pen, stop_pen, dyn_scale, rt1, rt2, rt3;
   int turn2, contra2, veh2, stop2, rt2_1, rt2_2, rt2_3;     // the same in half units (valid when `half`)
   bool half;
-  long long n_exp, n_relax;
+  long long n_exp, n_relax, n_exp_spill;   // n_exp_spill: expansions made while part of the heap sat in HBM
   int max_heap;
   long long prof[8], pt;
   __device__ __forceinline__ void xy_of(int cell, int& x, int& y) const {
@@ -396,6 +396,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
     }
     KP(3);
     C.n_exp++;
+    if constexpr (SPILL) C.n_exp_spill++;
     const int steps = C.limited ? (int)((m_c >> 2) & T_STEPS_MASK) : 0;
     const uint32_t bits = (uint32_t)rl((int)a_l, 4) & 15u;
     // ---- lane dd < 4 evaluates neighbour dd from what was fetched before the sift-down -------------------------
@@ -524,7 +525,7 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
     C.turn2 = (int)(C.turn_pen * 2.0); C.contra2 = (int)(C.contra_pen * 2.0); C.veh2 = (int)(C.veh_pen * 2.0); C.stop2 = (int)(C.stop_pen * 2.0);
     C.rt2_1 = (int)(C.rt1 * 2.0); C.rt2_2 = (int)(C.rt2 * 2.0); C.rt2_3 = (int)(C.rt3 * 2.0);
   }
-  C.n_exp = 0; C.n_relax = 0; C.max_heap = 0;
+  C.n_exp = 0; C.n_relax = 0; C.n_exp_spill = 0; C.max_heap = 0;
   for (int k = 0; k < 8; k++) C.prof[k] = 0;
   C.pt = clock64();
   // the chain of relaxations behind a heap entry never revisits a cell (dist strictly falls), so it is shorter than
@@ -559,6 +560,7 @@ __device__ int astar_wave(const Dev& d, const TsParams& P, AScratch& S, int star
   if (C.lane == 0) {   // profiling aid: deepest heap / longest search any searcher has seen (ts_debug_read words 4, 5)
     atomicMax(&d.cnt->dbg[4], C.max_heap);
     atomicMax(&d.cnt->dbg[5], (int)min(C.n_exp, (long long)0x7FFFFFFF));
+    if (C.n_exp_spill) atomicAdd((unsigned long long*)&d.cnt->dbg[6], (unsigned long long)C.n_exp_spill);   // (dbg[6..7] as one 64-bit count)
 #ifdef TS_KPROF
     for (int k = 0; k < 8; k++) d.cnt->prof[k] = C.prof[k];
 #endif

@@ -107,7 +107,8 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     if (getenv("TS_DEBUG_REPLAN")) {
       int dbg[8];
       HIPOK(hipMemcpy(dbg, d.cnt->dbg, sizeof(dbg), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[replan] deepest heap so far %d, longest search so far %d expansions\n", dbg[4], dbg[5]);
+      fprintf(stderr, "[replan] deepest heap so far %d, longest search so far %d expansions, %lld expansions so far with part of the heap in HBM\n",
+              dbg[4], dbg[5], (long long)(((unsigned long long)(unsigned)dbg[7] << 32) | (unsigned)dbg[6]));
     }
     if (e->hint[3] == TS_E_CAPACITY) return fail(e, TS_E_CAPACITY, "an A* search exceeded its heap or path buffers");
     const int retry = e->hint[8 + 4];
