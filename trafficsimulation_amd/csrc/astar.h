@@ -291,7 +291,7 @@ __device__ __forceinline__ int astar_loop(ACtx& C, int& heap_size) {
   const unsigned below_l = (1u << lane) - 1u;                      // (lanes 0-3 use it)
   while (heap_size > 0) {
     if (!SPILL && heap_size > LDS_HEAP - 4) return AL_SWITCH;        // this turn's pushes might not fit LDS
-    if (SPILL && heap_size < LDS_HEAP / 2) return AL_SWITCH;
+    if (SPILL && heap_size < LDS_HEAP - 96) return AL_SWITCH;      // (heaps breathe by a few entries per turn: a band of ~90 keeps the switches rare)
     KP(7);
     // one LDS read serves the root (lane 0; every lane gets it through readfirstlane) and the first sift-down window
     // (lanes 2..63: slots 1..62 - the window below a hole at the root): nothing has written to them in this turn yet
