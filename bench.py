@@ -243,7 +243,11 @@ def main():
     c0 = api.counters()
     barrier()
     t0 = time.perf_counter()
-    api.step(args.steps)   # ts_step returns only after the engine's stream has drained
+    tick_s = []
+    for _ in range(args.steps):   # ts_step returns only after the engine's stream has drained: one call per tick, to see the spread
+        ts = time.perf_counter()
+        api.step(1)
+        tick_s.append(time.perf_counter() - ts)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -316,6 +320,9 @@ def main():
                                    "replicated state, sharded replans (one world on all ranks, bit-exact)" if mode == "sharded"
                                    else "replicas (independent worlds, bit-exact)"),
                 "move_rounds_per_tick": rounds / args.steps, "bit_exact_vs_cpu_oracle": "tests/test_gpu_parity.py",
+                # (this rank's ticks: under the default policy every sixth one is a replanning wave, the others are bounded
+                # by their longest search)
+                "tick_ms": {"min": min(tick_s) * 1e3, "median": sorted(tick_s)[len(tick_s) // 2] * 1e3, "max": max(tick_s) * 1e3},
                 "warmup_seconds": warm_s,
             },
             "roofline": dict({
