@@ -1680,6 +1680,14 @@ int tso_add_vehicles_dirs(ts_handle e, int32_t n, const int32_t* start_xy, const
   return TS_OK;
 }
 
+int tso_remove_vehicle(ts_handle e, int32_t spawn_idx) {   // city_model.py:1920-1941, called between ticks
+  if (!e) return TS_E_INVALID;
+  if (spawn_idx < 0 || spawn_idx >= (int)e->veh.size() || !e->veh[spawn_idx].alive) { e->err = "no such live vehicle"; return TS_E_INVALID; }
+  if (e->veh[spawn_idx].svc_type) { e->err = "service vehicles cannot be removed by the host"; return TS_E_UNSUPPORTED; }
+  remove_vehicle(e, spawn_idx);
+  return TS_OK;
+}
+
 int tso_upload_map(ts_handle e, int32_t which, const int8_t* src) {
   if (!e || !src) return TS_E_INVALID;
   std::vector<int8_t>* m = which == TS_MAP_STOP ? &e->stop : which == TS_MAP_RAIN ? &e->rain : nullptr;

@@ -1,5 +1,5 @@
 """Randomised differential test of the C-ABI as a host drives it: a random sequence of calls - step a few ticks,
-spawn vehicles (with explicit paths or planned by the engine), write the stop map the way the UI's handlers do,
+spawn vehicles (with explicit paths or planned by the engine), remove vehicles, write the stop map the way the UI's handlers do,
 write the rain map, re-seed either stream (from an integer or from a captured state) - issued identically to the
 HIP engine and the CPU oracle, state compared after every call."""
 import os
@@ -58,7 +58,7 @@ def test_random_call_sequences(case):
     coff, cxy = np.asarray(tb["light_ctrl_off"]), np.asarray(tb["light_ctrl_xy"]).reshape(-1, 2)
     for op_i in range(60):
         op = rng.choice(["step", "step", "step", "spawn_paths", "spawn_plan", "stop", "rain", "seed_int", "seed_state",
-                         "rain_spawn", "group_links"])
+                         "rain_spawn", "group_links", "remove"])
         ctx = f"case {case} op {op_i} ({op})"
         if op == "step":
             n = int(rng.integers(1, 6))
@@ -73,6 +73,16 @@ def test_random_call_sequences(case):
                     e.add_vehicles_dirs(s[lo:hi], g[lo:hi], pop, off[lo:hi + 1] - off[lo], dirs[off[lo]:off[hi]])
                 else:
                     e.add_vehicles(s[lo:hi], g[lo:hi], pop)
+        elif op == "remove":
+            # CityModel.remove_vehicle from the host: a few live vehicles picked by their creation index leave at once
+            rows = a.vehicles()
+            if len(rows):
+                for idx in rng.choice(rows[:, 0], size=min(3, len(rows)), replace=False):
+                    a.remove_vehicle(int(idx)), b.remove_vehicle(int(idx))
+                with pytest.raises(capi.EngineError):
+                    a.remove_vehicle(int(idx))            # (gone already)
+                with pytest.raises(capi.EngineError):
+                    b.remove_vehicle(int(idx))
         elif op == "stop" and len(lights):
             # what CellAgent.set_light_stop / set_light_go do for a few lights (cell.py:241-251): edit + upload
             m = a.map(capi.MAP_STOP).copy()

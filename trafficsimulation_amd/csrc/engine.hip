@@ -1467,6 +1467,31 @@ int ts_add_vehicles_dirs(ts_handle e, int32_t n, const int32_t* start_xy, const 
   return add_vehicles_any(e, n, start_xy, goal_xy, population_type, nullptr, nullptr, path_off, path_dirs);
 }
 
+int ts_remove_vehicle(ts_handle e, int32_t spawn_idx) {
+  if (!e) return TS_E_INVALID;
+  if (spawn_idx < 0 || spawn_idx >= e->n_vehicles_total) return fail(e, TS_E_INVALID, "no such live vehicle");
+  Dev& d = e->d;
+  uint16_t fl = 0;
+  HIPOK(hipMemcpy(&fl, d.flags + spawn_idx, 2, hipMemcpyDeviceToHost));
+  if (!(fl & VF_ALIVE)) return fail(e, TS_E_INVALID, "no such live vehicle");
+  if (fl & VF_SVC) return fail(e, TS_E_UNSUPPORTED, "service vehicles cannot be removed by the host");
+  hipLaunchKernelGGL(k_remove_one, dim3(1), dim3(64), 0, e->stream, d, spawn_idx);
+  // the lists close up at once (the reference's list.remove / schedule.remove): the next tick shuffles the live keys
+  int na = 0, ns = 0;
+  int rc = compact(e, 0, e->n_active, &na); if (rc) return rc;
+  rc = compact(e, 1, e->n_sched, &ns); if (rc) return rc;
+  e->n_active = na; e->n_sched = ns; e->n_sched_vehicles -= 1;
+  if (e->clock_slot >= 0 && e->mixed_order) {
+    std::vector<int8_t> kinds(ns);
+    HIPOK(hipMemcpy(kinds.data(), d.sched_kind, ns, hipMemcpyDeviceToHost));
+    e->clock_slot = -1;
+    for (int q = 0; q < ns; q++) if (kinds[q] == TS_AGENT_CLOCK) { e->clock_slot = q; break; }
+  }
+  HIPOK(hipMemsetAsync(&d.cnt->deaths, 0, sizeof(int), e->stream));
+  e->amap_valid = false;
+  return sync_counters(e);
+}
+
 int ts_upload_map(ts_handle e, int32_t which, const int8_t* src) {
   if (!e || !src) return TS_E_INVALID;
   int8_t* m = which == TS_MAP_STOP ? e->d.stop : which == TS_MAP_RAIN ? e->d.rain : nullptr;

@@ -880,6 +880,13 @@ __global__ void k_decide_despawn(Dev d, TsParams P, int i_arrived, int i_skipped
     }
   }
 }
+// CityModel.remove_vehicle called by the host between ticks (ts_remove_vehicle)
+__global__ void k_remove_one(Dev d, int vid) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint16_t f = d.flags[vid];
+  remove_vehicle_dev(d, vid, d.sched_slot[vid], d.pos[vid], f, 0);
+  d.flags[vid] = f;
+}
 // (schedule slot, rank) of CityBlocks (which = 0, ids = block index) or vehicles (which = 1, ids = vehicle id)
 __global__ void k_gather_ranks(Dev d, const int32_t* ids, int n, int which, int32_t* out) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -866,6 +866,13 @@ class CityModel:
             c = self._cells[(x, y)] = CellAgent(self, x, y)
         return c
 
+    def remove_vehicle(self, vehicle, population_type: str = "undefined", vehicle_type: str = "undefined"):
+        """city_model.py:1920-1941 - between ticks: the vehicle leaves the grid, the schedule and the decide order
+        (the engine knows its population, the two string arguments are accepted for signature compatibility)."""
+        self.engine.remove_vehicle(vehicle._spawn_idx)
+        self._vehicles.pop(vehicle._spawn_idx, None)
+        self._invalidate()
+
     def get_cell_contents(self, x, y):
         return self.grid[x, y] if self.in_bounds(x, y) else []
 
