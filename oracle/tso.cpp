@@ -354,7 +354,19 @@ void update_density_fast(E* e) {
 // Verbatim semantics incl. both quirks of SURVEY §8(a) A13: (1) dir_arr is indexed by heap SLOT and
 // is not swapped by the sift routines; (2) `ng` is a float (R1 penalty 0.5) and truncates on store.
 // respect_awareness (FOV, astar_numba.py:29-50; off by default, config.py:278) is restated inside astar().
+#ifdef TSO_STATS
+// Profiling aid (profiles/heap_stats.py; built into a separate library, never into libtso.so): what the heaps of the
+// searches look like - heap size at every pop, levels the hole sinks / a push rises, searches by expansions.
+struct AStats { long long pop_size[64], sink[40], rise[40], relax_n[5], search_exp[40], pops, stale;
+                long long ext_n[32], ext_exp[32], empty_n[4], empty_exp[4], kind_n[4], kind_exp[4], maxheap_n[32], maxheap_exp[32], fspread[32]; };
+static AStats g_astats;
+static inline int bitlen(long long v) { int b = 0; while (v > 0) { b++; v >>= 1; } return b; }
+#define STAT(x) do { x; } while (0)
+#else
+#define STAT(x) do { } while (0)
+#endif
 inline void heap_sift_up(E* e, int i) {
+  int rise_ = 0; (void)rise_;
   while (i > 0) {
     int parent = (i - 1) / 2;
     if (e->hf[i] < e->hf[parent]) {
@@ -363,11 +375,13 @@ inline void heap_sift_up(E* e, int i) {
       std::swap(e->hs[i], e->hs[parent]);
       std::swap(e->hi[i], e->hi[parent]);
       i = parent;
+      STAT(rise_++);
     } else break;
   }
+  STAT(g_astats.rise[rise_ < 39 ? rise_ : 39]++);
 }
 inline void heap_sift_down(E* e, int size) {
-  int idx = 0;
+  int idx = 0, sink_ = 0; (void)sink_;
   for (;;) {
     int left = 2 * idx + 1, right = left + 1, smallest = idx;
     if (left < size && e->hf[left] < e->hf[smallest]) smallest = left;
@@ -378,8 +392,10 @@ inline void heap_sift_down(E* e, int size) {
       std::swap(e->hs[idx], e->hs[smallest]);
       std::swap(e->hi[idx], e->hi[smallest]);
       idx = smallest;
+      STAT(sink_++);
     } else break;
   }
+  STAT(g_astats.sink[sink_ < 39 ? sink_ : 39]++);
 }
 inline void heap_reserve(E* e, int n) {
   if ((int)e->hf.size() < n) {
@@ -427,9 +443,18 @@ void astar(E* e, int sx, int sy, int gx, int gy, bool soft, bool ignore_flow, in
   int heap_size = 1;
   e->hf[0] = std::abs(sx - gx) + std::abs(sy - gy);
   e->hg[0] = 0; e->hs[0] = 0; e->hi[0] = start_idx; e->hdir[0] = -1;
+  long long exp0_ = e->C.astar_expansions; (void)exp0_;
+  int ext_ = 0, maxheap_ = 0; (void)ext_; (void)maxheap_;
+  struct StatEnd { int64_t& c; long long c0; int& ext; int& mh; std::vector<int>& out; int kind;
+    ~StatEnd() { STAT(const long long n = c - c0; g_astats.search_exp[bitlen(n)]++; const int b = ext / 32 < 31 ? ext / 32 : 31;
+                      g_astats.ext_n[b]++; g_astats.ext_exp[b] += n; g_astats.kind_n[kind]++; g_astats.kind_exp[kind] += n;
+                      const int hb = mh / 64 < 31 ? mh / 64 : 31; g_astats.maxheap_n[hb]++; g_astats.maxheap_exp[hb] += n;
+                      if (out.empty()) { g_astats.empty_n[kind]++; g_astats.empty_exp[kind] += n; }); } }
+    stat_end_{e->C.astar_expansions, exp0_, ext_, maxheap_, out, (soft ? 1 : 0) + (ignore_flow ? 2 : 0)};
   while (heap_size > 0) {
     int g = e->hg[0], steps = e->hs[0], cur = e->hi[0];
     int prev_dir = e->hdir[0];
+    STAT(g_astats.pops++; g_astats.pop_size[heap_size < 64 * 64 ? heap_size / 64 : 63]++);
     heap_size--;
     if (heap_size > 0) {
       e->hf[0] = e->hf[heap_size]; e->hg[0] = e->hg[heap_size]; e->hs[0] = e->hs[heap_size];
@@ -442,9 +467,11 @@ void astar(E* e, int sx, int sy, int gx, int gy, bool soft, bool ignore_flow, in
       std::reverse(out.begin(), out.end());
       return;
     }
-    if (g > dist_get(cur)) continue;
+    if (g > dist_get(cur)) { STAT(g_astats.stale++); continue; }
     e->C.astar_expansions++;
     const int cx = cur % W, cy = cur / W;
+    int nrel_ = 0; (void)nrel_;
+    struct StatRel { int& n; ~StatRel() { STAT(g_astats.relax_n[n]++); } } stat_rel_{nrel_};
     for (int d = 0; d < 4; d++) {
       int nx = cx + DX[d], ny = cy + DY[d];
       if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
@@ -478,6 +505,8 @@ void astar(E* e, int sx, int sy, int gx, int gy, bool soft, bool ignore_flow, in
       }
       if (ng < (double)dist_get(nidx)) {
         e->C.astar_relaxations++;
+        STAT(nrel_++; ext_ = std::max(ext_, std::max(std::abs(nx - sx), std::abs(ny - sy))); maxheap_ = std::max(maxheap_, heap_size + 1);
+             { int fs = (int)(ng + (std::abs(nx - gx) + std::abs(ny - gy))) - e->hf[0]; if (heap_size > 0) g_astats.fspread[bitlen(fs < 0 ? 0 : fs)]++; });
         dist_set(nidx, (int)ng, cur);
         int h = std::abs(nx - gx) + std::abs(ny - gy);
         int i = heap_size;
@@ -1896,4 +1925,7 @@ int tso_debug_set_occupancy(ts_handle e, const int8_t* src) {
   return TS_OK;
 }
 
+#ifdef TSO_STATS
+void tso_stats_read(long long* out) { memcpy(out, &g_astats, sizeof g_astats); }   // 64 + 40 + 40 + 5 + 40 + 2 words
+#endif
 }  // extern "C"

@@ -33,7 +33,11 @@ namespace {
 
 constexpr int A_INF = 0x3F3F3F3F;
 constexpr int MAXB = 64;  // longest contraflow bypass (VEHICLE_MAX_CONTRAFLOW_*_STEPS <= 64)
-enum { DV_DONE = 0, DV_DEFER = 1, DV_OVERFLOW = 2, DV_POOL_FULL = 3 };
+enum { DV_DONE = 0, DV_DEFER = 1, DV_OVERFLOW = 2, DV_POOL_FULL = 3, DV_SUSPEND = 4, DV_BAIL = 5 };
+// Who runs a vehicle's step_decide: one lane without scratch (k_decide_main: bails out as soon as a search is needed), one
+// wavefront (k_replan: every lane the same code on the same values, searches spread over the wave), or one quad of four
+// lanes (k_replan_quad, astar_quad.h: sixteen vehicles per wave, their searches advancing in lockstep)
+enum { DM_LANE = 0, DM_WAVE = 1, DM_QUAD = 2 };
 
 // heap slots (and dir bytes) a searcher keeps in LDS: 6.2 KB, twenty-four searchers per CU (736 entries already cost occupancy) (the deepest heap seen on
 // 1024^2 - 4096^2 runs is ~2100 entries; what does not fit spills to the searcher's HBM scratch)
@@ -70,6 +74,13 @@ struct AScratch {
   int cap;        // capacity of the cell buffers
   int use_reach;  // phase 1 asks reach_strict_wave before it searches (off: TS_NO_REACH, a debugging switch)
   long long calls, expansions, relaxations;
+  // DM_QUAD only (astar_quad.h): the policy code is re-run from the top after every search (it is a pure function of the
+  // tick-start state and of its searches' results until the final commit), taking finished searches from this log and
+  // suspending at the first one that is not in it
+  int q_status, q_replay, q_done;          // DV_SUSPEND / DV_BAIL when a planner returns false; searches replayed / finished
+  int32_t* q_log;                          // per finished search: path length, expansions, relaxations
+  int q_start, q_goal, q_soft, q_cap;      // the search the policy is waiting for
+  int32_t* q_out;
 };
 struct RLists { int32_t* l[6]; };       // replan work lists, see run_replans (engine.hip)
 
@@ -95,6 +106,7 @@ __device__ __forceinline__ void scratch_bind(const ASlots& t, int slot, AScratch
   S.use_reach = t.use_reach;
   S.epoch = t.slot_epoch[slot];
   S.calls = 0; S.expansions = 0; S.relaxations = 0;
+  S.q_status = 0; S.q_replay = 0; S.q_done = 0; S.q_log = nullptr; S.q_start = 0; S.q_goal = 0; S.q_soft = 0; S.q_cap = 0; S.q_out = nullptr;
 }
 // Work-queue order of the replans (largest first).  Per vehicle the bit length of the expansions its last replan took is
 // kept (Dev::tier_hint); the four classes are ranges of it (< 2 048, < 32 768, < 262 144 expansions, more), and inside a
@@ -734,16 +746,30 @@ __device__ __forceinline__ void swap_ptr(int32_t*& a, int32_t*& b) { int32_t* t 
 
 // _compute_path_internal (vehicle_base.py:199-420).  On success the result is in S.P[0..*out_len) (possibly
 // empty).  Returns false on tier overflow.
-// WAVE: the caller runs with all 64 lanes of its wave executing the same code on the same values (one vehicle per
+// DM_WAVE: the caller runs with all 64 lanes of its wave executing the same code on the same values (one vehicle per
 // wave); plain stores are then harmless duplicates, atomics are issued by lane 0 only, and the searches use
-// astar_wave.  !WAVE: one vehicle per lane (k_decide_main), nothing is shared.
-template <bool WAVE>
+// astar_wave.  DM_QUAD: the same with the four lanes of a quad.  DM_LANE: one vehicle per lane (k_decide_main), nothing is shared.
+constexpr int QLOG = 8;   // searches one step_decide can make in quad mode (beyond that the vehicle goes to k_replan)
+template <int MODE>
 __device__ __forceinline__ int astar_any(const Dev& d, const TsParams& P, AScratch& S, int start_idx, int goal_idx, bool soft,
                                          bool ignore_flow, int maximum_steps, int32_t* out, int out_cap) {
-  if constexpr (WAVE) return astar_wave(d, P, S, start_idx, goal_idx, soft, ignore_flow, maximum_steps, out, out_cap);
-  else return -1;   // (one vehicle per lane never searches: decide_vehicle<false> defers before it gets here)
+  if constexpr (MODE == DM_WAVE) return astar_wave(d, P, S, start_idx, goal_idx, soft, ignore_flow, maximum_steps, out, out_cap);
+  else if constexpr (MODE == DM_QUAD) {
+    const int k = S.q_replay++;
+    if (k < S.q_done) {   // finished in an earlier pass: its path already sits in `out`
+      S.calls++; S.expansions += S.q_log[3 * k + 1]; S.relaxations += S.q_log[3 * k + 2];
+      return S.q_log[3 * k];
+    }
+    // the quad searcher carries neither step limits nor contraflow (bypass searches are rare and small): such a vehicle is
+    // handed to k_replan, as is one that searches more often than the log is long
+    if (maximum_steps < d.N || ignore_flow || k >= QLOG) { S.q_status = DV_BAIL; return -1; }
+    S.q_start = start_idx; S.q_goal = goal_idx; S.q_soft = soft ? 1 : 0; S.q_out = out; S.q_cap = out_cap;
+    S.q_status = DV_SUSPEND;
+    return -1;
+  }
+  else return -1;   // (one vehicle per lane never searches: decide_vehicle<DM_LANE> defers before it gets here)
 }
-template <bool WAVE>
+template <int MODE>
 __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScratch& S, VW& v, int& out_len) {
   // ---- phase 0: re-merge with the saved original path (219-277) ----
   for (int which = 0; which < 2; which++) {
@@ -758,7 +784,7 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
       if (d.cell[c].occ == 0) { merge_idx = q; b = c; break; }
     }
     if (merge_idx < 0) continue;
-    int bl = astar_any<WAVE>(d, P, S, v.pos, b, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
+    int bl = astar_any<MODE>(d, P, S, v.pos, b, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
     if (bl < 0) return false;
     if (bl > 0 && S.BYP[bl - 1] == b) {
       int n = 0;
@@ -778,18 +804,18 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
   const int sx_goal = v.target;
   int la;
   bool unreachable = false;
-  if constexpr (WAVE) unreachable = v.reach_known && reach_strict_wave(d, S, v.pos, sx_goal) == 2;
+  if constexpr (MODE == DM_WAVE) unreachable = v.reach_known && reach_strict_wave(d, S, v.pos, sx_goal) == 2;
   if (unreachable) {
     // the frontier BFS proved the target unreachable under the strict rules: the search would flood its whole
     // component and return [] (astar_numba.py:239).  Same result, without the flood.
     S.calls++;
     la = 0;
   } else {
-    la = astar_any<WAVE>(d, P, S, v.pos, sx_goal, false, false, 0x7FFFFFFF, S.A, S.cap);
+    la = astar_any<MODE>(d, P, S, v.pos, sx_goal, false, false, 0x7FFFFFFF, S.A, S.cap);
     if (la < 0) return false;
   }
   if (la == 0) {
-    la = astar_any<WAVE>(d, P, S, v.pos, sx_goal, true, false, 0x7FFFFFFF, S.A, S.cap);
+    la = astar_any<MODE>(d, P, S, v.pos, sx_goal, true, false, 0x7FFFFFFF, S.A, S.cap);
     if (la < 0) return false;
   }
   // ---- phase 3: contraflow overtake of a stranded / parked blocker (309-366) ----
@@ -807,7 +833,7 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
         int bt = -1, idx_bp = -1;
         for (int q = 0; q < la; q++) if (d.cell[S.A[q]].occ == 0) { bt = S.A[q]; idx_bp = q; break; }
         if (bt >= 0) {
-          int bl = astar_any<WAVE>(d, P, S, v.pos, bt, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
+          int bl = astar_any<MODE>(d, P, S, v.pos, bt, false, true, P.max_contraflow_overtake_steps, S.BYP, MAXB);
           if (bl < 0) return false;
           if (bl > 1 && S.BYP[bl - 1] == bt) {
             // idx_bp = first index of bt in path = the index found above (first free cell)
@@ -837,7 +863,7 @@ __device__ bool compute_path_internal_dev(const Dev& d, const TsParams& P, AScra
       int bt = -1, merge_idx = -1;
       for (int q = 0; q < la; q++) if (d.cell[S.A[q]].occ == 0) { bt = S.A[q]; merge_idx = q; break; }
       if (bt >= 0) {
-        int bl = astar_any<WAVE>(d, P, S, v.pos, bt, true, true, P.max_contraflow_stuck_detour_steps, S.BYP, MAXB);
+        int bl = astar_any<MODE>(d, P, S, v.pos, bt, true, true, P.max_contraflow_stuck_detour_steps, S.BYP, MAXB);
         if (bl < 0) return false;
         if (bl > 1 && S.BYP[bl - 1] == bt) {
           int n = 0;
@@ -879,11 +905,15 @@ __device__ bool ax_contains(const Dev& d, const AScratch* S, const VW& v, int k,
 }
 
 // device-side bump allocation in the path pool; returns false when the pool is exhausted
-template <bool WAVE>
+// (quad_perm [0,0,0,0]: every lane of a quad reads its lane 0)
+__device__ __forceinline__ int quad_first(int v) { return __builtin_amdgcn_mov_dpp(v, 0x00, 0xF, 0xF, true); }
+template <int MODE>
 __device__ __forceinline__ bool pool_alloc(const Dev& d, int words, uint32_t& off) {
   unsigned long long o = 0;
-  if (!WAVE || lane_id() == 0) o = atomicAdd((unsigned long long*)&d.cnt->pool_used, (unsigned long long)words);
-  if (WAVE) o = ((unsigned long long)(unsigned)__shfl((int)(o >> 32), 0) << 32) | (unsigned)__shfl((int)(unsigned)o, 0);
+  const bool one = MODE == DM_LANE || (MODE == DM_WAVE ? lane_id() == 0 : (lane_id() & 3) == 0);
+  if (one) o = atomicAdd((unsigned long long*)&d.cnt->pool_used, (unsigned long long)words);
+  if (MODE == DM_WAVE) o = ((unsigned long long)(unsigned)__shfl((int)(o >> 32), 0) << 32) | (unsigned)__shfl((int)(unsigned)o, 0);
+  if (MODE == DM_QUAD) o = ((unsigned long long)(unsigned)quad_first((int)(o >> 32)) << 32) | (unsigned)quad_first((int)(unsigned)o);
   if (o + (unsigned long long)words > (unsigned long long)d.pool_cap_words) return false;
   off = (uint32_t)o;
   return true;
@@ -904,9 +934,9 @@ __device__ void encode_cells(const Dev& d, uint32_t off, int start_cell, const i
 
 // step_decide for vehicle number i of active_vehicle_agents.  S == nullptr: run until a search is needed
 // (returns DV_DEFER without side effects).  Otherwise completes, unless the tier overflows or the pool is full.
-template <bool WAVE>
+template <int MODE>
 __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* S) {
-  const bool one = !WAVE || lane_id() == 0;   // the lane that issues this vehicle's atomics
+  const bool one = MODE == DM_LANE || (MODE == DM_WAVE ? lane_id() == 0 : (lane_id() & 3) == 0);   // the lane that issues this vehicle's atomics
   const int vid = d.active[i];
   if (vid < 0) return DV_DONE;
   VW v;
@@ -962,7 +992,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
       if (!S) return DV_DEFER;
       v.cooldown = P.pathfinding_cooldown;
       int len;
-      if (!compute_path_internal_dev<WAVE>(d, P, *S, v, len)) return DV_OVERFLOW;
+      if (!compute_path_internal_dev<MODE>(d, P, *S, v, len)) return MODE == DM_QUAD ? S->q_status : DV_OVERFLOW;
       v.newpath = true; v.plen = len; path_changed = true;
     }
     // _recompute_path_on_obstacle (454-504)
@@ -999,7 +1029,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
       v.cooldown = P.pathfinding_cooldown;
       const bool keep_new = v.newpath;
       int len;
-      if (!compute_path_internal_dev<WAVE>(d, P, *S, v, len)) return DV_OVERFLOW;
+      if (!compute_path_internal_dev<MODE>(d, P, *S, v, len)) return MODE == DM_QUAD ? S->q_status : DV_OVERFLOW;
       if (len > 0) {
         v.newpath = true; v.plen = len; path_changed = true;
         scan_ahead_dev(d, P, S, v, idx_stop, idx_veh, first_cell);
@@ -1027,7 +1057,7 @@ __device__ int decide_vehicle(const Dev& d, const TsParams& P, int i, AScratch* 
     int words = path_changed ? (v.plen + 15) / 16 : 0;
     for (int k = 0; k < 4; k++) if (v.ax_staged[k]) words += (v.ax_len[k] + 15) / 16;
     uint32_t off = 0;
-    if (words > 0 && !pool_alloc<WAVE>(d, words, off)) return DV_POOL_FULL;
+    if (words > 0 && !pool_alloc<MODE>(d, words, off)) return DV_POOL_FULL;
     uint8_t chg = 0;
     if (path_changed) {
       encode_cells(d, off, v.pos, S->P, v.plen);
@@ -1086,7 +1116,7 @@ __global__ void k_decide_main(Dev d, TsParams P, int lo, int n_active, RLists li
   int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_active) return;
   if (d.cnt->rng_event != 0xFFFFFFFFu) return;  // a malfunction / sideswipe fired: the host re-runs this after the fix-up
-  if (decide_vehicle<false>(d, P, i, nullptr) == DV_DEFER) {
+  if (decide_vehicle<DM_LANE>(d, P, i, nullptr) == DV_DEFER) {
     // work-queue class (largest first): what the vehicle's last replan cost, or what a search over this distance is
     // likely to cost
     const int h = cost_class_of_bits(replan_cost_bits(d, d.active[i]));
@@ -1130,7 +1160,7 @@ __device__ __attribute__((noinline)) int replan_turn(const Dev& d, const TsParam
   i = uni(i);
   if (q.world > 1 && (i % q.world) != q.rank) return 1;
   const long long c0 = S->calls, e0 = S->expansions, r0 = S->relaxations;
-  const int r = uni(decide_vehicle<true>(d, P, i, S));
+  const int r = uni(decide_vehicle<DM_WAVE>(d, P, i, S));
   if (threadIdx.x == 0) {
     if (r == DV_DONE) {  // work of attempts that are re-run after pool growth is not counted twice
       const int vid = d.active[i];
@@ -1152,12 +1182,13 @@ __device__ __attribute__((noinline)) int replan_turn(const Dev& d, const TsParam
 // full go to `retry_list` (counter replan_n[4]); replan_n[5] is the queue cursor.
 // `world` > 1: the replicated-state multi-GPU mode - this rank plans only the vehicles whose decide-order index is
 // congruent to `rank`; the results travel through ts_replan_export / ts_replan_import.
+// `class_mask`: the class lists this launch serves (the others belong to k_replan_quad, astar_quad.h).
 TS_REPLAN_OCC __global__ void __launch_bounds__(64) k_replan(Dev d, TsParams P, ASlots sl, RLists lists, int32_t* retry_list, int rank, int world,
-                                               int32_t* owned_list) {
+                                               int32_t* owned_list, int class_mask) {
   AScratch S;
   scratch_bind(sl, blockIdx.x, S);
   RQueue q;
-  for (int c = 0; c < 4; c++) { q.l[c] = lists.l[c]; q.n[c] = d.cnt->replan_n[c]; }
+  for (int c = 0; c < 4; c++) { q.l[c] = lists.l[c]; q.n[c] = ((class_mask >> c) & 1) ? d.cnt->replan_n[c] : 0; }
   q.retry_list = retry_list; q.owned_list = owned_list; q.rank = rank; q.world = world;
   while (uni(replan_turn(d, P, &S, q))) {}
   if (threadIdx.x == 0) sl.slot_epoch[blockIdx.x] = S.epoch;
@@ -1271,13 +1302,13 @@ TS_REPLAN_OCC __global__ void __launch_bounds__(64) k_spawn_plan(Dev d, TsParams
   v.reach_known = false;
   for (int k = 0; k < 4; k++) { v.ax_staged[k] = false; v.ax_len[k] = d.ax_len[k][vid]; }
   int len;
-  bool ok = compute_path_internal_dev<true>(d, P, S, v, len);
+  bool ok = compute_path_internal_dev<DM_WAVE>(d, P, S, v, len);
   if (one) sl.slot_epoch[0] = S.epoch;
   if (!ok) { if (one) *status = -1; return; }
   int words = (len + 15) / 16;
   for (int k = 0; k < 4; k++) if (v.ax_staged[k]) words += (v.ax_len[k] + 15) / 16;
   uint32_t off = 0;
-  if (words > 0 && !pool_alloc<true>(d, words, off)) { if (one) *status = -2; return; }
+  if (words > 0 && !pool_alloc<DM_WAVE>(d, words, off)) { if (one) *status = -2; return; }
   if (one) {
     atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
     atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);

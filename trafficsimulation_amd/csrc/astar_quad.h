@@ -1,0 +1,417 @@
+// astar_quad.h - the replanning searches, sixteen to a wavefront (k_replan_quad).
+//
+// k_replan (astar.h) spreads ONE search over the 64 lanes of a wave: ~160 vector + ~150 scalar instructions per expansion,
+// issued for one expansion's worth of work (profiles/r02_sq_replan_2048.json).  Here a search owns a QUAD of four lanes -
+// lane j of the quad is direction j of astar_numba.py's neighbour loop (N, E, S, W) - and the sixteen quads of a wave run
+// sixteen independent searches through one branch-light loop in lockstep: every instruction issued serves sixteen
+// expansions, nothing is wave-uniform (no scalar unit work beyond loop control), and the cross-lane traffic is quad_perm
+// DPP, which is free.  The algorithm is astar_core's, slot for slot and compare for compare:
+//   * heap: the reference's binary heap as 8-byte (f, cell) entries, the first TS_QUAD_LCAP slots of every search in LDS
+//     (16 x 316 x 8 B = 39.5 KB per wave, four waves per CU), deeper slots in the search's HBM spill.  Sift-down: lanes
+//     0 / 1 of the quad fetch the hole's two children, one DPP swap shows each its sibling's key, "my entry moves up" is
+//     one compare (strict '<', ties to the parent, then to the left child: astar_numba.py:67-85).  Sift-up: the four lanes
+//     fetch four ancestors of the new slot at once (52-65);
+//   * dir_arr (indexed by heap SLOT, never moved by the sifts: the stale-slot quirk) is only ever read at the heap's
+//     last slot and written at the slots behind it - a stack.  Two bits per slot, the 32 slots around the heap's end in
+//     a register pair, the rest in HBM; slot 0 in a register of its own;
+//   * dist / came_from: one 4-byte record per CELL (dist 22 bits | direction 2 | epoch stamp 8) in a table that is a
+//     1024 x 1024-cell window addressed by the cell's coordinates modulo the window (8 x 8-tiled): the record's address
+//     does not depend on the map entry, so both loads of an expansion leave together (k_replan's node-numbered table costs
+//     a dependent second round trip), and a searcher costs 4 MB instead of 8 bytes per road cell of the whole map.  A
+//     search that relaxes a cell 512 or more columns / rows away from its start, whose g reaches 2^22, whose heap outgrows
+//     the spill or whose path outgrows the buffers is abandoned, and its vehicle goes to k_replan's queue (nothing of it
+//     has been committed: step_decide is a pure function of the tick-start state until its last lines);
+//   * half-unit integer costs only (astar_half_units: the reference's defaults), no step limit, no contraflow, no
+//     field-of-view mask: the searches that need those (bypasses: a few hundred expansions each, rare) take the vehicle to
+//     k_replan as well.
+// The policy around the searches (decide_vehicle<DM_QUAD>: step_decide with _compute_path_internal's phases) is run by the
+// quad like k_replan runs it by the wave - every lane the same code on the same values - but it cannot keep a search on its
+// call stack while fifteen other quads advance theirs.  It is re-run from the top after every search instead: finished
+// searches are taken from a log (length + counters; their paths already sit in the buffers the policy handed out), the
+// first unfinished one suspends the pass (DV_SUSPEND) and becomes the quad's search.
+#pragma once
+#include "astar.h"
+
+namespace {
+
+#ifndef TS_QUAD_LCAP
+#define TS_QUAD_LCAP 316
+#endif
+#ifndef TS_QUAD_WAVES_PER_CU
+#define TS_QUAD_WAVES_PER_CU 4
+#endif
+constexpr int QL = TS_QUAD_LCAP;            // heap slots per search in LDS (and the stride between two searches' heaps)
+// (bank spread: the 8-byte slots of the eight quads of a half-wave at the same heap index must fall into different banks)
+static_assert(QL % 8 == 4, "TS_QUAD_LCAP must be 4 mod 8 (LDS bank spread between the quads of a wave)");
+static_assert((size_t)16 * QL * 8 * TS_QUAD_WAVES_PER_CU <= 160 * 1024 - 512, "the LDS heaps of TS_QUAD_WAVES_PER_CU waves must fit a CU");
+constexpr int QT_LOG_MAX = 10;              // table window: at most 1024 x 1024 cells
+constexpr int Q_CELLS = 4096;               // path buffer capacity per search (cells)
+constexpr int Q_SPILL = 7936;               // heap slots per search beyond LDS (HBM)
+constexpr uint32_t Q_DIST_MASK = (1u << 22) - 1, Q_STAMP_SHIFT = 24, Q_DIR_SHIFT = 22;
+enum { QS_NEEDJOB = 0, QS_POLICY = 1, QS_SEARCH = 2, QS_FOUND = 3, QS_EMPTY = 4, QS_ABANDON = 5, QS_IDLE = 6 };
+
+struct QSlots {
+  int n_slots;            // searches = quads: sixteen per wave
+  int tw_log, th_log;     // table window: 2^tw_log x 2^th_log cells (the whole map when it is smaller)
+  int chk_x, chk_y;       // the map is wider / taller than the window: relaxations are bounded to the window around the start
+  size_t tab_entries;     // per slot
+  uint32_t* tab;
+  unsigned long long* gq; // per slot Q_SPILL entries
+  uint32_t* gdw;          // per slot (QL + Q_SPILL) / 16 + 4 words of 2-bit directions
+  int32_t* cells;         // per slot 5 * Q_CELLS + 3 * MAXB
+  int32_t* log;           // per slot 3 * QLOG
+  uint32_t* slot_epoch;
+};
+constexpr int Q_DWORDS = (QL + Q_SPILL) / 16 + 4;
+
+__shared__ unsigned long long q_lds[16 * QL];
+
+// quad_perm DPP: lane j of every quad reads lane P[j] of its quad
+template <int CTRL> __device__ __forceinline__ int qperm(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+constexpr int QP_SWAP1 = 0xB1;   // [1,0,3,2]
+constexpr int QP_SWAP2 = 0x4E;   // [2,3,0,1]
+constexpr int QP_B0 = 0x00, QP_B1 = 0x55, QP_B2 = 0xAA, QP_B3 = 0xFF;   // broadcasts of lane 0 .. 3
+__device__ __forceinline__ int quad_or(int v) {   // OR over the four lanes of the quad, in every lane
+  v |= qperm<QP_SWAP1>(v);
+  v |= qperm<QP_SWAP2>(v);
+  return v;
+}
+
+// what a quad keeps about its search while the lockstep loop runs (every lane of the quad holds the same values)
+struct QState {
+  int hs;                   // heap_size
+  int dir0;                 // dir_arr[0]
+  int wb;                   // first slot of the direction window (a multiple of 16)
+  unsigned long long dwin;  // dir_arr[wb .. wb + 32), two bits per slot
+  int gx, gy, sx, sy;
+  uint32_t goal_xy;         // x | y << 16
+  uint32_t stamp;           // epoch << 24
+  int soft;
+  int n_exp, n_relax;
+};
+struct QConst {   // per quad, fixed for the kernel's lifetime
+  TS_GLOBAL uint32_t* tab;
+  gu64p gq;
+  TS_GLOBAL uint32_t* gdw;
+  int lbase;                // first slot of this quad's heap in q_lds
+  int j;                    // lane of the quad = neighbour direction
+  int dx, dy;
+  // wave-uniform
+  const TS_GLOBAL u64* amap;
+  int W, H, W8, twm, thm, tw8_log, chk_x, chk_y, half_w, half_h;
+  int turn2, stop2, rt2_1, rt2_2, rt2_3;
+  bool turn_on, rt_on;
+};
+
+__device__ __forceinline__ uint32_t q_tix(const QConst& K, int x, int y) {
+  const uint32_t xm = (uint32_t)x & (uint32_t)K.twm, ym = (uint32_t)y & (uint32_t)K.thm;
+  return ((((ym >> 3) << K.tw8_log) + (xm >> 3)) << 6) | ((ym & 7u) << 3) | (xm & 7u);
+}
+__device__ __forceinline__ uint32_t q_aix(const QConst& K, int x, int y) {
+  return (((__umul24((uint32_t)(y >> 3), (uint32_t)K.W8) + (uint32_t)(x >> 3)) << 6) | (uint32_t)((y & 7) << 3) | (uint32_t)(x & 7));
+}
+__device__ __forceinline__ u64 q_hget(const QConst& K, int k) {
+  u64 v;
+  if (k < QL) v = q_lds[K.lbase + k]; else v = K.gq[k - QL];
+  return v;
+}
+__device__ __forceinline__ void q_hput(const QConst& K, int k, u64 v) {
+  if (k < QL) q_lds[K.lbase + k] = v; else K.gq[k - QL] = v;
+}
+
+// One turn of astar_core's main loop (astar_numba.py:136-237) for every quad whose search is on.  Returns the quad's
+// new state: QS_SEARCH, QS_FOUND (the goal was popped), QS_EMPTY (heap empty: `return []`) or QS_ABANDON.
+__device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
+  if (s.hs <= 0) return QS_EMPTY;
+  const int j = K.j;
+  // ---- the direction window follows the heap's end: slots hs - 1 (read by this pop) .. hs + 2 (written by its pushes)
+  if (s.hs + 2 > s.wb + 31) {
+    K.gdw[s.wb >> 4] = (uint32_t)s.dwin;
+    s.dwin = (s.dwin >> 32) | ((u64)K.gdw[(s.wb >> 4) + 2] << 32);
+    s.wb += 16;
+  } else if (s.hs - 1 < s.wb) {
+    K.gdw[(s.wb >> 4) + 1] = (uint32_t)(s.dwin >> 32);
+    s.dwin = (s.dwin << 32) | (u64)K.gdw[(s.wb >> 4) - 1];
+    s.wb -= 16;
+  }
+  // ---- pop (138-148)
+  const u64 root = q_lds[K.lbase];
+  const int last_i = s.hs - 1;
+  const u64 x = q_hget(K, last_i);
+  const int f_top = hq_f(root);
+  const uint32_t cxy = (uint32_t)hq_i(root);
+  const int cx = (int)(cxy & 0xFFFFu), cy = (int)(cxy >> 16);
+  const int prev_dir = s.dir0;
+  const int xd = (int)((s.dwin >> (2 * ((last_i - s.wb) & 31))) & 3ull);
+  s.hs = last_i;
+  // everything the expansion reads from HBM leaves now and travels while the sift-down works: lane j the map entry and
+  // the table record of neighbour j, every lane (one request) the popped cell's own
+  const int nx = cx + K.dx, ny = cy + K.dy;
+  const bool inb = (unsigned)nx < (unsigned)K.W && (unsigned)ny < (unsigned)K.H;
+  const uint32_t a_ix = inb ? q_aix(K, nx, ny) : q_aix(K, cx, cy);
+  const uint32_t t_ix = inb ? q_tix(K, nx, ny) : q_tix(K, cx, cy);
+  const u64 am_l = ld8(K.amap, a_ix);
+  const uint32_t t_l = K.tab[t_ix];
+  const uint32_t am_c = (uint32_t)ld8(K.amap, q_aix(K, cx, cy));
+  const uint32_t t_c = K.tab[q_tix(K, cx, cy)];
+  if (last_i > 0) {
+    s.dir0 = xd;
+    // heap_sift_down (67-85): the last entry sinks from the root
+    const int xf = hq_f(x);
+    const int side = j & 1;          // lanes 0 / 2 look at the left child, 1 / 3 at the right one
+    int p = 0;
+    for (;;) {
+      const int c = 2 * p + 1 + side;
+      const bool valid = c < last_i;
+      u64 e = 0;
+      if (valid) e = q_hget(K, c);
+      const int ef = valid ? hq_f(e) : 0x7FFFFFFF;
+      const int sf = qperm<QP_SWAP1>(ef);
+      // smallest of (x, left, right), ties to x, then to left: my entry moves up iff ef < xf and (left: ef <= sf, right: ef < sf)
+      const bool win = (unsigned)ef < min((unsigned)xf, (unsigned)sf + (unsigned)(side ^ 1));
+      const int w = quad_or(win ? (1 << j) : 0) & 3;    // (lanes 2 / 3 mirror 0 / 1)
+      if (w == 0) break;
+      if (win && j < 2) q_hput(K, p, e);
+      p = 2 * p + 1 + (w >> 1);
+    }
+    if (j == 0) q_hput(K, p, x);
+  }
+  wave_mem_sync();
+  if (cxy == s.goal_xy) return QS_FOUND;   // (151: before the staleness test)
+  const int g = f_top - (abs(cx - s.gx) + abs(cy - s.gy));
+  {
+    const int dist_c = ((t_c ^ s.stamp) >> Q_STAMP_SHIFT) == 0u ? (int)(t_c & Q_DIST_MASK) : A_INF;
+    if (g > dist_c) return QS_SEARCH;      // (165)
+  }
+  s.n_exp++;
+  // ---- lane j evaluates neighbour j (171-225) in half units, exactly as astar_loop<HALF> does
+  const uint32_t a_l = (uint32_t)am_l;
+  const bool node_l = (uint32_t)(am_l >> 32) != 0xFFFFFFFFu;
+  const int dist_l = ((t_l ^ s.stamp) >> Q_STAMP_SHIFT) == 0u ? (int)(t_l & Q_DIST_MASK) : A_INF;
+  const bool n_occ = ((a_l >> 8) & 1u) != 0u, n_stop = ((a_l >> 9) & 1u) != 0u, n_road = ((a_l >> 4) & 1u) != 0u;
+  const uint32_t rt = (a_l >> 6) & 3u;
+  const bool flow = ((am_c >> j) & 1u) != 0u;
+  const bool turn = K.turn_on & (prev_dir != -1) & (j != prev_dir);
+  int n2 = 2 * (g + 1);
+  n2 += turn ? K.turn2 : 0;
+  n2 += n_occ ? (int)(a_l >> AMAP_PEN_SHIFT) : 0;
+  n2 += n_stop ? K.stop2 : 0;
+  const int rtp = rt == 1u ? K.rt2_1 : rt == 2u ? K.rt2_2 : rt == 3u ? K.rt2_3 : 0;
+  n2 += (K.rt_on & n_road) ? rtp : 0;
+  const bool ok = inb & node_l & flow & ((s.soft != 0) | !(n_occ | n_stop)) & (n2 < 2 * dist_l);
+  const int ngi = n2 >> 1;
+  // what this searcher cannot carry: a g beyond the record's 22 bits, a cell the table window would alias
+  bool bad = ok & (ngi > (int)Q_DIST_MASK);
+  if (K.chk_x) bad |= ok & (abs(nx - s.sx) >= K.half_w);
+  if (K.chk_y) bad |= ok & (abs(ny - s.sy) >= K.half_h);
+  const int relax = quad_or((ok ? (1 << j) : 0) | (bad ? 16 : 0));
+  if (relax & 16) return QS_ABANDON;
+  if (relax == 0) return QS_SEARCH;
+  const int n_new = __builtin_popcount((unsigned)relax);
+  if (s.hs + n_new > QL + Q_SPILL) return QS_ABANDON;
+  s.n_relax += n_new;
+  if (ok) K.tab[t_ix] = (uint32_t)ngi | ((uint32_t)j << Q_DIR_SHIFT) | s.stamp;   // dist / came_from (226-227)
+  const int nf_l = ngi + abs(nx - s.gx) + abs(ny - s.gy);
+  const int nxy_l = (int)((uint32_t)nx | ((uint32_t)ny << 16));
+  // ---- heap pushes in the reference's order N, E, S, W (229-237)
+  auto push = [&](int dd, int nf, int nxy) {
+    const int i = s.hs;
+    if (i == 0) s.dir0 = dd;
+    else {
+      const int sh = 2 * ((i - s.wb) & 31);
+      s.dwin = (s.dwin & ~(3ull << sh)) | ((u64)(unsigned)dd << sh);
+    }
+    // heap_sift_up (52-65): the four lanes fetch four ancestors of slot i at a time; ancestor k = ((i + 1) >> k) - 1
+    const int depth = 31 - __builtin_clz((unsigned)(i + 1));
+    int rise = 0;
+    for (int base = 0; base < depth; base += 4) {
+      const int k = base + 1 + j;
+      const bool has = k <= depth;
+      const int a = (int)(((unsigned)(i + 1) >> (k & 31)) - 1u);
+      u64 anc = 0;
+      if (has) anc = q_hget(K, a);
+      const bool up = has & (nf < hq_f(anc));
+      const int um = quad_or(up ? (1 << j) : 0);
+      const int cnt = __builtin_ctz(~(unsigned)um);      // the entry passes a PREFIX of its ancestors (heap order)
+      if (up) q_hput(K, (int)(((unsigned)(i + 1) >> ((k - 1) & 31)) - 1u), anc);   // ancestor k moves to where k - 1 was
+      rise += cnt;
+      if (cnt < 4) break;
+    }
+    if (j == 0) q_hput(K, (int)(((unsigned)(i + 1) >> (rise & 31)) - 1u), hq_pack(nf, nxy));
+    s.hs = i + 1;
+    wave_mem_sync();
+  };
+  if (relax & 1) push(0, qperm<QP_B0>(nf_l), qperm<QP_B0>(nxy_l));
+  if (relax & 2) push(1, qperm<QP_B1>(nf_l), qperm<QP_B1>(nxy_l));
+  if (relax & 4) push(2, qperm<QP_B2>(nf_l), qperm<QP_B2>(nxy_l));
+  if (relax & 8) push(3, qperm<QP_B3>(nf_l), qperm<QP_B3>(nxy_l));
+  return QS_SEARCH;
+}
+
+struct QReq { int start, goal, soft, cap; int32_t* out; };
+struct QQueue { int32_t* l[4]; int n[4]; int32_t *retry_list, *fallback_list, *owned_list; int rank, world; };
+
+__device__ __forceinline__ void quad_scratch_bind(const QSlots& qs, int slot, AScratch& S) {
+  S.tab = nullptr; S.gq = nullptr; S.gd = nullptr; S.heap_cap = 0; S.epoch = 0;
+  int32_t* c = qs.cells + (size_t)slot * ((size_t)5 * Q_CELLS + 3 * MAXB);
+  S.A = c; S.P = c + Q_CELLS; S.T = c + 2 * Q_CELLS; S.PO = c + 3 * Q_CELLS; S.PD = c + 4 * Q_CELLS;
+  S.BYP = c + 5 * Q_CELLS; S.OV = S.BYP + MAXB; S.DV = S.OV + MAXB;
+  S.cap = Q_CELLS;
+  S.use_reach = 0;
+  S.calls = 0; S.expansions = 0; S.relaxations = 0;
+  S.q_log = qs.log + (size_t)slot * (3 * QLOG);
+  S.q_status = DV_BAIL; S.q_replay = 0; S.q_done = 0;
+  S.q_start = 0; S.q_goal = 0; S.q_soft = 0; S.q_cap = 0; S.q_out = nullptr;
+}
+
+// One pass of vehicle i's step_decide by the quad (see the header: re-run from the top after every search).  Kept out of
+// line like replan_turn.
+__device__ __attribute__((noinline)) int quad_policy(const Dev& d, const TsParams& P, const QSlots& qs, const QQueue& q, int slot, int i,
+                                                     int n_done, QReq& req) {
+  AScratch S;
+  quad_scratch_bind(qs, slot, S);
+  S.q_done = n_done;
+  const int r = decide_vehicle<DM_QUAD>(d, P, i, &S);
+  const bool one = (threadIdx.x & 3) == 0;
+  if (r == DV_SUSPEND) {
+    req.start = S.q_start; req.goal = S.q_goal; req.soft = S.q_soft; req.cap = S.q_cap; req.out = S.q_out;
+  } else if (one) {
+    if (r == DV_DONE) {
+      const int vid = d.active[i];
+      if (S.calls > 0) d.tier_hint[vid] = (uint8_t)cost_bits(S.expansions);
+      atomicAdd((unsigned long long*)&d.cnt->astar_calls, (unsigned long long)S.calls);
+      atomicAdd((unsigned long long*)&d.cnt->astar_exp, (unsigned long long)S.expansions);
+      atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
+      if (q.owned_list) q.owned_list[atomicAdd(&d.cnt->replan_n[6], 1)] = i;
+    } else if (r == DV_POOL_FULL) q.retry_list[atomicAdd(&d.cnt->replan_n[4], 1)] = i;
+    else q.fallback_list[atomicAdd(&d.cnt->quad_n[0], 1)] = i;     // DV_BAIL, DV_OVERFLOW: k_replan takes the vehicle
+  }
+  return r;
+}
+
+// Replanning vehicles, sixteen per wave: a work queue like k_replan's (class lists `class_mask` selects, most expensive
+// first; cursor quad_n[1]).  Every quad takes entries until the queue is empty; vehicles this searcher cannot carry go
+// to `fallback_list` (counter quad_n[0]) for k_replan.
+__global__ void __launch_bounds__(64) k_replan_quad(Dev d, TsParams P, QSlots qs, RLists lists, int class_mask, int32_t* retry_list,
+                                                    int32_t* fallback_list, int rank, int world, int32_t* owned_list) {
+  const int lane = (int)threadIdx.x, j = lane & 3;
+  const int slot = (int)blockIdx.x * 16 + (lane >> 2);
+  const bool one = j == 0;
+  QQueue q;
+  for (int c = 0; c < 4; c++) { q.l[c] = lists.l[c]; q.n[c] = ((class_mask >> c) & 1) ? d.cnt->replan_n[c] : 0; }
+  q.retry_list = retry_list; q.fallback_list = fallback_list; q.owned_list = owned_list; q.rank = rank; q.world = world;
+  const int n3 = q.n[3], n2 = q.n[2], n1 = q.n[1], n0 = q.n[0];
+  QConst K;
+  K.tab = (TS_GLOBAL uint32_t*)(uintptr_t)(qs.tab + (size_t)slot * qs.tab_entries);
+  K.gq = (gu64p)(uintptr_t)(qs.gq + (size_t)slot * Q_SPILL);
+  K.gdw = (TS_GLOBAL uint32_t*)(uintptr_t)(qs.gdw + (size_t)slot * Q_DWORDS);
+  K.lbase = (lane >> 2) * QL;
+  K.j = j;
+  K.dx = (j == 1) - (j == 3); K.dy = (j == 0) - (j == 2);
+  K.amap = (const TS_GLOBAL u64*)(uintptr_t)uni64((u64)(uintptr_t)d.amap);
+  K.W = uni(d.W); K.H = uni(d.H); K.W8 = uni(d.W8);
+  K.twm = (1 << qs.tw_log) - 1; K.thm = (1 << qs.th_log) - 1; K.tw8_log = qs.tw_log - 3;
+  K.chk_x = qs.chk_x; K.chk_y = qs.chk_y; K.half_w = 1 << (qs.tw_log - 1); K.half_h = 1 << (qs.th_log - 1);
+  K.turn_on = P.turn_penalty_enabled != 0; K.rt_on = P.road_type_penalties_enabled != 0;
+  K.turn2 = (int)((double)P.turn_penalty * 2.0); K.stop2 = (int)((double)P.obstacle_penalty_stop * 2.0);
+  K.rt2_1 = (int)((double)P.road_type_penalty_r1 * 2.0); K.rt2_2 = (int)((double)P.road_type_penalty_r2 * 2.0);
+  K.rt2_3 = (int)((double)P.road_type_penalty_r3 * 2.0);
+  uint32_t epoch = qs.slot_epoch[slot];
+  QState s;
+  s.hs = 0; s.dir0 = -1; s.wb = 0; s.dwin = 0; s.gx = s.gy = s.sx = s.sy = 0; s.goal_xy = 0; s.stamp = 0; s.soft = 0; s.n_exp = 0; s.n_relax = 0;
+  QReq req;
+  req.start = req.goal = req.soft = req.cap = 0; req.out = nullptr;
+  int st = QS_NEEDJOB, job = -1, n_done = 0;
+  for (;;) {
+    // ---------------- per quad: everything that is not a search turn ----------------
+    while (st != QS_SEARCH && st != QS_IDLE) {
+      if (st == QS_FOUND || st == QS_EMPTY) {
+        // the search the policy waited for is over: its path (start excluded, goal included: 151-162) goes where the
+        // policy asked for it, its length and counters into the log
+        int len = 0;
+        if (st == QS_FOUND) {
+          const TS_GLOBAL uint32_t* tab = K.tab;
+          gi32p outg = (gi32p)(uintptr_t)req.out;
+          int px = (int)(s.goal_xy & 0xFFFFu), py = (int)(s.goal_xy >> 16);
+          while (px != s.sx || py != s.sy) {
+            if (len >= req.cap) { len = -1; break; }
+            outg[req.cap - 1 - len] = py * K.W + px;
+            len++;
+            const int dd = (int)((tab[q_tix(K, px, py)] >> Q_DIR_SHIFT) & 3u);
+            px -= (dd == 1) - (dd == 3); py -= (dd == 0) - (dd == 2);
+          }
+          wave_mem_sync();
+          const int shift = req.cap - len;
+          if (len > 0 && shift > 0)
+            for (int k0 = 0; k0 < len; k0 += 4) {
+              const int k = k0 + j;
+              const int v = k < len ? outg[shift + k] : 0;
+              if (k < len) outg[k] = v;
+            }
+          wave_mem_sync();
+        }
+        if (len < 0) st = QS_ABANDON;
+        else {
+          int32_t* lg = qs.log + (size_t)slot * (3 * QLOG) + 3 * n_done;
+          lg[0] = len; lg[1] = s.n_exp; lg[2] = s.n_relax;
+          n_done++;
+          st = QS_POLICY;
+        }
+      }
+      if (st == QS_ABANDON) {
+        if (one) fallback_list[atomicAdd(&d.cnt->quad_n[0], 1)] = job;
+        st = QS_NEEDJOB;
+      }
+      if (st == QS_NEEDJOB) {
+        int t = 0;
+        if (one) t = atomicAdd(&d.cnt->quad_n[1], 1);
+        t = quad_first(t);
+        if (t >= n3 + n2 + n1 + n0) { st = QS_IDLE; break; }
+        int i;
+        if (t < n3) i = q.l[3][t];
+        else if (t < n3 + n2) i = q.l[2][t - n3];
+        else if (t < n3 + n2 + n1) i = q.l[1][t - n3 - n2];
+        else i = q.l[0][t - n3 - n2 - n1];
+        if (world > 1 && (i % world) != rank) continue;
+        job = i; n_done = 0;
+        st = QS_POLICY;
+      }
+      if (st == QS_POLICY) {
+        const int r = quad_policy(d, P, qs, q, slot, job, n_done, req);
+        if (r != DV_SUSPEND) { st = QS_NEEDJOB; continue; }
+        // ---- a fresh search (113-128): new epoch for the table, start record, one-entry heap
+        epoch++;
+        if (epoch > 255u) {
+          const size_t n = qs.tab_entries;
+          for (size_t t = (size_t)j; t < n; t += 4) K.tab[t] = 0u;
+          epoch = 1;
+          wave_mem_sync();
+        }
+        int gxx, gyy, sxx, syy;
+        cell_xy(d, req.goal, gxx, gyy); cell_xy(d, req.start, sxx, syy);
+        s.gx = gxx; s.gy = gyy; s.sx = sxx; s.sy = syy;
+        s.goal_xy = (uint32_t)gxx | ((uint32_t)gyy << 16);
+        s.stamp = epoch << Q_STAMP_SHIFT;
+        s.soft = req.soft;
+        s.n_exp = 0; s.n_relax = 0;
+        s.dir0 = -1; s.wb = 0; s.dwin = 0;
+        if (one) {
+          K.tab[q_tix(K, sxx, syy)] = s.stamp;    // dist 0
+          q_lds[K.lbase] = hq_pack(abs(sxx - gxx) + abs(syy - gyy), (int)((uint32_t)sxx | ((uint32_t)syy << 16)));
+        }
+        s.hs = 1;
+        wave_mem_sync();
+        st = QS_SEARCH;
+      }
+    }
+    const unsigned long long act = ballot(st == QS_SEARCH);
+    if (act == 0ull) break;
+    // ---------------- the searches of the wave advance in lockstep until one of them ends ----------------
+    do {
+      if (st == QS_SEARCH) st = quad_turn(K, s);
+    } while (ballot(st == QS_SEARCH) == act);
+  }
+  if (one) qs.slot_epoch[slot] = epoch;
+}
+
+}  // namespace

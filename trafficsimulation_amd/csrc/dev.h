@@ -37,6 +37,7 @@ struct DevCnt {
   int arr_n;       // service records written this tick (Dev::arr)
   int error;       // sticky device-side error
   int replan_n[8]; // replanning work queue: [0..3] class list lengths, [4] pool-full retries, [5] queue cursor, [6] entries this rank planned
+  int quad_n[4];   // k_replan_quad: [0] vehicles handed back to k_replan, [1] its queue cursor
   unsigned long long pool_used;  // words handed out from the path pool (device-side bump allocator)
   long long astar_calls, astar_exp, astar_relax;
   long long errored_internal, errored_through;   // _despawn_check removals

@@ -37,6 +37,7 @@
 
 #include "dev.h"
 #include "astar.h"
+#include "astar_quad.h"
 #include "kernels.h"
 #include "host_state.h"
 #include "host_shuffle.h"
@@ -95,11 +96,61 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     HIPOK(hipcub::DeviceRadixSort::SortPairs(e->sort_tmp, tmp_bytes, e->sort_keys, e->sort_keys_alt, e->replan_list[h], e->sort_vals_alt, n, 0, REPLAN_KEY_BITS, st));
     HIPOK(hipMemcpyAsync(e->replan_list[h], e->sort_vals_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
   }
+  // First pass, when the parameters allow the quad searcher: the classes below QUAD_CLASS_MASK's top go to k_replan_quad
+  // (sixteen searches per wave, on its own stream), the most expensive class to k_replan beside it (its searches are the
+  // tick's tail and want the faster single search); what the quads hand back, and what found the pool full, is queued again
+  // for k_replan below.
+  if (e->quad_on && replan_pending(e->hint + 8) > 0) {
+    static const int quad_mask = getenv("TS_QUAD_CLASSES") ? atoi(getenv("TS_QUAD_CLASSES")) & 15 : 7;
+    int nq = 0, nw = 0;
+    for (int c = 0; c < 4; c++) { if ((quad_mask >> c) & 1) nq += e->hint[8 + c]; else nw += e->hint[8 + c]; }
+    const double tl = now_ms();
+    HIPOK(hipMemsetAsync(d.cnt->quad_n, 0, sizeof(int) * 4, st));
+    int tok = prof_begin(e, PK_REPLAN, nq + nw);
+    if (nq > 0) {
+      HIPOK(hipEventRecord(e->quad_ev0, st));
+      HIPOK(hipStreamWaitEvent(e->quad_stream, e->quad_ev0, 0));
+      const int grid = std::min((nq + 15) / 16, e->qslots.n_slots / 16);
+      if (g_trace_launches) { fprintf(stderr, "[launch] k_replan_quad items=%d grid=%d\n", nq, grid); fflush(stderr); }
+      hipLaunchKernelGGL(k_replan_quad, dim3(grid), dim3(64), 0, e->quad_stream, d, P, e->qslots, rl, quad_mask, e->replan_list[4],
+                         e->replan_list[5], e->dist_rank, e->dist_world, e->dist_world > 1 ? e->owned_list : nullptr);
+      HIPOK(hipEventRecord(e->quad_ev1, e->quad_stream));
+    }
+    if (nw > 0)
+      hipLaunchKernelGGL(k_replan, dim3(std::min(nw, e->slots.n_slots)), dim3(64), 0, st, d, P, e->slots, rl, e->replan_list[4], e->dist_rank,
+                         e->dist_world, e->dist_world > 1 ? e->owned_list : nullptr, 15 & ~quad_mask);
+    if (nq > 0) HIPOK(hipStreamWaitEvent(st, e->quad_ev1, 0));
+    prof_end(e, tok);
+    int qn[4] = {0, 0, 0, 0};
+    HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+    HIPOK(hipMemcpyAsync(e->hint + 3, &d.cnt->error, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPOK(hipMemcpyAsync(qn, d.cnt->quad_n, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    if (g_trace_launches) { fprintf(stderr, "[done] first replanning pass\n"); fflush(stderr); }
+    if (e->hint[3] == TS_E_CAPACITY) return fail(e, TS_E_CAPACITY, "an A* search exceeded its heap or path buffers");
+    const int fb = qn[0], retry = e->hint[8 + 4];
+    e->quad_jobs += nq; e->quad_fallbacks += fb;
+    if (getenv("TS_DEBUG_REPLAN"))
+      fprintf(stderr, "[replan] tick %lld: %d entries to the quads (%d slots), %d to k_replan; handed back %d, pool-full %d, %.2f ms\n",
+              (long long)e->C.step_count, nq, e->qslots.n_slots, nw, fb, retry, now_ms() - tl);
+    if (retry > 0) {
+      d.pool_cap_words = e->pool_cap;
+      rc = pool_make_room(e, (size_t)retry * 1024 + (1u << 20));
+      if (rc) return rc;
+    }
+    // the second pass' queue: list 0 = handed-back entries, then the pool-full ones
+    if (fb > 0) HIPOK(hipMemcpyAsync(e->replan_list[0], e->replan_list[5], (size_t)fb * 4, hipMemcpyDeviceToDevice, st));
+    if (retry > 0) HIPOK(hipMemcpyAsync(e->replan_list[0] + fb, e->replan_list[4], (size_t)retry * 4, hipMemcpyDeviceToDevice, st));
+    const int keep_owned = e->hint[8 + 6];
+    for (int q = 0; q < 8; q++) e->hint[8 + q] = 0;
+    e->hint[8] = fb + retry; e->hint[8 + 6] = keep_owned;
+    HIPOK(hipMemcpyAsync(d.cnt->replan_n, e->hint + 8, sizeof(int) * 8, hipMemcpyHostToDevice, st));
+  }
   while (replan_pending(e->hint + 8) > 0) {
     const int n = replan_pending(e->hint + 8);
     const int grid = std::min(n, e->slots.n_slots);
     LAUNCH(e, PK_REPLAN, n, k_replan, dim3(grid), dim3(64), d, P, e->slots, rl, e->replan_list[4], e->dist_rank, e->dist_world,
-           e->dist_world > 1 ? e->owned_list : nullptr);
+           e->dist_world > 1 ? e->owned_list : nullptr, 15);
     const double tl = now_ms();
     HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
     HIPOK(hipMemcpyAsync(e->hint + 3, &d.cnt->error, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1013,6 +1064,9 @@ int ts_destroy(ts_handle e) {
   if (e->h_take) (void)hipHostFree(e->h_take);
   if (e->words_ev) (void)hipEventDestroy(e->words_ev);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  if (e->quad_stream) { (void)hipStreamSynchronize(e->quad_stream); (void)hipStreamDestroy(e->quad_stream); }
+  if (e->quad_ev0) (void)hipEventDestroy(e->quad_ev0);
+  if (e->quad_ev1) (void)hipEventDestroy(e->quad_ev1);
   if (e->hint) (void)hipHostFree(e->hint);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   uint32_t* hw = e->h_words;
