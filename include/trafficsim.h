@@ -318,11 +318,13 @@ int ts_add_vehicles_dirs(ts_handle h, int32_t n, const int32_t* start_xy, const 
 
 /* CityModel.remove_vehicle (city_model.py:1920-1941) called by the host between ticks: vehicle `spawn_idx` (the creation
  * index that ts_download_vehicles reports in column 0) leaves the maps (occupancy and stuck_map of its cell are cleared,
- * even if another vehicle shares the cell), the cell's MultiGrid list, the schedule and active_vehicle_agents; live_internal /
- * live_through drop by one.  As in the reference nothing else is touched (a stuck or parked vehicle stays counted in
- * `stuck` / `parked`).  TS_E_INVALID: no such live vehicle; TS_E_UNSUPPORTED: a service vehicle (its block / load
+ * even if another vehicle shares the cell), the cell's MultiGrid list, the schedule and active_vehicle_agents.  The live
+ * counters follow the CALLER's `population_type` argument like the reference's do (1935-1941: 'internal' -> live_internal,
+ * 'through' -> live_through, the default 'undefined' -> neither), not the vehicle's own population: pass TS_POP_INTERNAL /
+ * TS_POP_THROUGH / TS_POP_UNDEFINED.  As in the reference nothing else is touched (a stuck or parked vehicle stays counted
+ * in `stuck` / `parked`).  TS_E_INVALID: no such live vehicle; TS_E_UNSUPPORTED: a service vehicle (its block / load
  * bookkeeping lives in ServiceVehicleAgent, which has no such entry in the reference). */
-int ts_remove_vehicle(ts_handle h, int32_t spawn_idx);
+int ts_remove_vehicle(ts_handle h, int32_t spawn_idx, int32_t population_type);
 
 /* Host writes between ticks (UI handlers / RainManager): whole-map upload of stop_map or
  * rain_map (cell.py:241-251, rain.py:156-184). */

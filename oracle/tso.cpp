@@ -541,7 +541,7 @@ bool tick_stranded(E* e, Vehicle& v) {  // vehicle_base.py:552-565
   return v.stranded();
 }
 
-void remove_vehicle(E* e, int vid);
+void remove_vehicle(E* e, int vid, int pop_arg = -1);
 
 void start_service(E* e, int vid);
 
@@ -562,14 +562,15 @@ void on_target_reached(E* e, int vid) {  // vehicle_base.py:755-775; vehicle_ser
   else if (!v.is_parked) { v.is_parked = true; e->C.parked++; }
 }
 
-void remove_vehicle(E* e, int vid) {  // city_model.py:1920-1941
+void remove_vehicle(E* e, int vid, int pop_arg) {  // city_model.py:1920-1941 (pop_arg: the caller's population_type argument; -1 = the vehicle's own, as _despawn passes it)
   Vehicle& v = e->veh[vid];
   e->occ[v.pos] = 0; e->stuck[v.pos] = 0;
   for (size_t i = 0; i < e->active.size(); i++) if (e->active[i] == vid) { e->active[i] = -1; break; }
   cell_remove(e, v.pos, vid);
   e->sched[e->veh_sched[vid]].alive = false;
-  if (v.pop_type == TS_POP_INTERNAL) e->C.live_internal--;
-  else if (v.pop_type == TS_POP_THROUGH) {
+  const int pop = pop_arg >= 0 ? pop_arg : v.pop_type;
+  if (pop == TS_POP_INTERNAL) e->C.live_internal--;
+  else if (pop == TS_POP_THROUGH) {
     e->C.live_through--;
     if (v.svc_type == TS_TRIP_SERVICE_FOOD) e->C.live_service_food--;
     else if (v.svc_type == TS_TRIP_SERVICE_WASTE) e->C.live_service_waste--;
@@ -1709,11 +1710,11 @@ int tso_add_vehicles_dirs(ts_handle e, int32_t n, const int32_t* start_xy, const
   return TS_OK;
 }
 
-int tso_remove_vehicle(ts_handle e, int32_t spawn_idx) {   // city_model.py:1920-1941, called between ticks
+int tso_remove_vehicle(ts_handle e, int32_t spawn_idx, int32_t population_type) {   // city_model.py:1920-1941, called between ticks
   if (!e) return TS_E_INVALID;
   if (spawn_idx < 0 || spawn_idx >= (int)e->veh.size() || !e->veh[spawn_idx].alive) { e->err = "no such live vehicle"; return TS_E_INVALID; }
   if (e->veh[spawn_idx].svc_type) { e->err = "service vehicles cannot be removed by the host"; return TS_E_UNSUPPORTED; }
-  remove_vehicle(e, spawn_idx);
+  remove_vehicle(e, spawn_idx, population_type == TS_POP_INTERNAL || population_type == TS_POP_THROUGH ? population_type : TS_POP_UNDEFINED);
   return TS_OK;
 }
 

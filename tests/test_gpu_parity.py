@@ -271,7 +271,6 @@ def test_hip_vs_oracle_full_size_4096_1m():
     _compare(h, c, 6, every=3)
 
 
-@pytest.mark.skipif(not os.environ.get("TS_BIG_TESTS"), reason="BASELINE config 5's size: about five minutes (TS_BIG_TESTS=1)")
 def test_hip_vs_oracle_config5_size_8192_4m():
     """BASELINE config 5's size on ONE GPU: 8192 x 8192, 4 x 10^6 vehicles + 3.3 x 10^5 QUEUE_ACTUATED light groups (more
     than 2^22 scheduled agents: 24-bit ranks in the claim words), replans gated off; the decide phase runs in four passes
@@ -387,3 +386,32 @@ def test_hip_vs_oracle_long_run_word_ring_wraps():
     epochs wrap too."""
     h, c = _pair(512, 50_000, 21, {"TRAFFIC_LIGHT_AGENT_ALGORITHM": "QUEUE_ACTUATED"})
     _compare(h, c, 400, every=25)
+
+
+
+@pytest.mark.parametrize("name", ["full_96_s8", "default_200_s20", "faults_64_s9", "startgoal_96_s27"])
+def test_hip_quad_searcher_reproduces_reference_trace(monkeypatch, name):
+    """k_replan_quad (astar_quad.h: sixteen searches per wave; opt-in, TS_QUAD=1) with k_replan beside it on the hand-backs,
+    forced on for every tick of a captured run: the same per-tick comparison against the reference's recorded state."""
+    from trafficsimulation_amd._lib import new_engine
+    monkeypatch.setenv("TS_QUAD", "1")
+    monkeypatch.setenv("TS_QUAD_MIN", "1")
+    api = new_engine()
+    try:
+        tr = load_trace(trace_path(name))
+        setup_from_trace(api, tr, explicit_paths=False)
+        n = replay_and_compare(api, tr)
+        assert n == len(tr["veh_off"]) - 1
+        assert api.counters().astar_calls == int(tr["astar_calls_spawn"]) + int(tr["astar_per_tick"].sum())
+    finally:
+        api.close()
+
+
+def test_hip_quad_searcher_vs_oracle_512_through_a_replanning_wave(monkeypatch):
+    """... and against the oracle on 512 x 512 / 12 000 vehicles through the first replanning wave (heaps beyond the quads'
+    LDS share, hand-backs to k_replan while both kernels run, the direction window moving), state for state every tick."""
+    monkeypatch.setenv("TS_QUAD", "1")
+    monkeypatch.setenv("TS_QUAD_MIN", "1")
+    h, c = _pair_full(512, 12_000, 7)
+    ch = _compare_full(h, c, 9)
+    assert ch.astar_calls > 5_000 and ch.astar_expansions > 1_000_000

@@ -78,7 +78,9 @@ def test_random_call_sequences(case):
             rows = a.vehicles()
             if len(rows):
                 for idx in rng.choice(rows[:, 0], size=min(3, len(rows)), replace=False):
-                    a.remove_vehicle(int(idx)), b.remove_vehicle(int(idx))
+                    # (the live counters follow the caller's population_type argument, 'undefined' by default)
+                    ptype = int(rng.choice([capi.POP["undefined"], capi.POP["internal"], capi.POP["through"]]))
+                    a.remove_vehicle(int(idx), ptype), b.remove_vehicle(int(idx), ptype)
                 with pytest.raises(capi.EngineError):
                     a.remove_vehicle(int(idx))            # (gone already)
                 with pytest.raises(capi.EngineError):

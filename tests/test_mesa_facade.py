@@ -297,3 +297,26 @@ def test_facade_display_names_match_reference(oracle, tag):
     assert inter.get_display_name() == f"Intersection_{inter.position[0]}_{inter.position[1]}"
     assert m.block_entrances[0].is_block_entrance() and m.highway_exits[0].is_highway_exit()
     assert m.highway_entrances[0].is_highway_entrance() and m.controlled_roads[0].is_controlled_road()
+
+
+def test_remove_vehicle_counts_the_callers_population_type(oracle):
+    """CityModel.remove_vehicle (city_model.py:1920-1941) decrements live_internal / live_through by the `population_type`
+    the CALLER passes - 'undefined' by default, i.e. neither - not by the vehicle's own population."""
+    import json
+    tr = load_trace(trace_path("dta_64_s12"))
+    m = CityModel(64, 64, seed=11, defaults=tr["defaults_json"], engine=oracle, traffic=json.loads(str(tr["dta_params"])))
+    for _ in range(40):
+        m.step()
+    vs = [v for v in m.active_vehicle_agents if not getattr(v, "is_service", False)][:3]
+    assert len(vs) == 3
+    c0 = m.engine.counters()
+    m.remove_vehicle(vs[0])                                   # defaults: 'undefined'
+    c1 = m.engine.counters()
+    assert (c1.live_internal, c1.live_through) == (c0.live_internal, c0.live_through)
+    m.remove_vehicle(vs[1], population_type="internal")
+    c2 = m.engine.counters()
+    assert (c2.live_internal, c2.live_through) == (c0.live_internal - 1, c0.live_through)
+    m.remove_vehicle(vs[2], "through", "undefined")
+    c3 = m.engine.counters()
+    assert (c3.live_internal, c3.live_through) == (c0.live_internal - 1, c0.live_through - 1)
+    assert len(m.active_vehicle_agents) == len([v for v in m.active_vehicle_agents])

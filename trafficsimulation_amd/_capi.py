@@ -226,7 +226,7 @@ class CApi:
         f("rng_state").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_uint32)]
         f("add_vehicles").argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
         f("add_vehicles_dirs").argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
-        f("remove_vehicle").argtypes = [C.c_void_p, C.c_int32]
+        f("remove_vehicle").argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         f("upload_map").argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         f("step").argtypes = [C.c_void_p, C.c_int32]
         f("download_map").argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -419,9 +419,10 @@ class CApi:
         self._chk(self._f("add_vehicles_dirs")(self.h, n, s.ctypes.data, g.ctypes.data, pt.ctypes.data,
                                                 po.ctypes.data, pd.ctypes.data))
 
-    def remove_vehicle(self, spawn_idx: int):
-        """CityModel.remove_vehicle between ticks; `spawn_idx` = column 0 of vehicles()."""
-        self._chk(self._f("remove_vehicle")(self.h, int(spawn_idx)))
+    def remove_vehicle(self, spawn_idx: int, population_type: int = 0):
+        """CityModel.remove_vehicle between ticks; `spawn_idx` = column 0 of vehicles().  `population_type` (POP[...]) is the
+        reference's argument of that name: the live counter it names drops by one, 'undefined' (the default) touches none."""
+        self._chk(self._f("remove_vehicle")(self.h, int(spawn_idx), int(population_type)))
 
     def upload_map(self, which: int, arr):
         a = np.ascontiguousarray(arr, dtype=np.int8)

@@ -55,7 +55,11 @@ constexpr int LDS_HEAP = TS_LDS_HEAP;
 #define TS_REPLAN_OCC __attribute__((amdgpu_waves_per_eu(TS_REPLAN_WAVES, 8)))
 struct __attribute__((aligned(8))) HQ { int32_t f, i; };             // heap entry: f_arr, i_arr (g_arr / s_arr: see above)
 struct __attribute__((aligned(8))) TEnt { int32_t dist; uint32_t meta; };   // meta = stamp << 14 | steps << 2 | came-from direction
-constexpr uint32_t T_STAMP_SHIFT = 14, T_STEPS_MASK = 0xFFF, T_STAMP_MAX = (1u << 18) - 1;
+// (TS_DEBUG_STAMP_MAX: a test build that wraps the searcher tables' epochs every few hundred searches instead of every 262 143)
+#ifndef TS_DEBUG_STAMP_MAX
+#define TS_DEBUG_STAMP_MAX ((1u << 18) - 1)
+#endif
+constexpr uint32_t T_STAMP_SHIFT = 14, T_STEPS_MASK = 0xFFF, T_STAMP_MAX = TS_DEBUG_STAMP_MAX;
 constexpr int A_STEPS_MAX = (int)T_STEPS_MASK - 1;   // largest binding step limit a search can carry (a limit >= N never binds)
 
 __shared__ unsigned long long g_lq[LDS_HEAP];   // packed HQ: f in the low word, cell in the high word
@@ -1144,16 +1148,43 @@ __global__ void k_replan_keys(Dev d, const int32_t* list, int n, uint32_t* keys)
 // k_replan's loop, hipcc 7.2 threaded the lane-0-only parts (queue pop, accounting) of consecutive turns together and
 // let lane 0 run the loop on a path of its own, apart from the other 63 lanes - wrong for code whose lanes cooperate
 // through readlane / ballot.  A call boundary is a point where the wave is whole again.
-struct RQueue { int32_t* l[4]; int n[4]; int32_t *retry_list, *owned_list; int rank, world; };
+struct RQueue {
+  int32_t* l[4]; int n[4]; int32_t *retry_list, *owned_list; int rank, world;
+  // vehicles k_replan_quad (astar_quad.h) hands back while both kernels run: entries appear in fb_list (-1 = not yet
+  // written; tickets from quad_n[2]) until all fb_waves quad waves have counted themselves out in quad_n[3]
+  int32_t* fb_list; int fb_waves, fb_cap;   // fb_cap: entries the quads were given = the most they can hand back
+};
 __device__ __attribute__((noinline)) int replan_turn(const Dev& d, const TsParams& P, AScratch* S, const RQueue& q) {
   const int n3 = uni(q.n[3]), n2 = uni(q.n[2]), n1 = uni(q.n[1]), n0 = uni(q.n[0]);
   if (threadIdx.x == 0) g_job = atomicAdd(&d.cnt->replan_n[5], 1);
   __syncthreads();
   const int j = uni(g_job);
   __syncthreads();
-  if (j >= n3 + n2 + n1 + n0) return 0;
   int i;
-  if (j < n3) i = q.l[3][j];
+  if (j >= n3 + n2 + n1 + n0) {
+    if (q.fb_waves == 0) return 0;
+    // this launch's own lists are done: take a ticket for the hand-back list and wait for its entry - or for the
+    // quads to finish without ever writing it
+    if (threadIdx.x == 0) {
+      const int t = atomicAdd(&d.cnt->quad_n[2], 1);
+      int job = -1;
+      while (t < q.fb_cap) {
+        job = __hip_atomic_load(&q.fb_list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (job >= 0) break;
+        if (__hip_atomic_load(&d.cnt->quad_n[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= q.fb_waves) {
+          job = __hip_atomic_load(&q.fb_list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (published before the count)
+          break;
+        }
+        __builtin_amdgcn_s_sleep(64);
+      }
+      g_job = job;
+    }
+    __syncthreads();
+    i = uni(g_job);
+    __syncthreads();
+    if (i < 0) return 0;
+  }
+  else if (j < n3) i = q.l[3][j];
   else if (j < n3 + n2) i = q.l[2][j - n3];
   else if (j < n3 + n2 + n1) i = q.l[1][j - n3 - n2];
   else i = q.l[0][j - n3 - n2 - n1];
@@ -1184,12 +1215,13 @@ __device__ __attribute__((noinline)) int replan_turn(const Dev& d, const TsParam
 // congruent to `rank`; the results travel through ts_replan_export / ts_replan_import.
 // `class_mask`: the class lists this launch serves (the others belong to k_replan_quad, astar_quad.h).
 TS_REPLAN_OCC __global__ void __launch_bounds__(64) k_replan(Dev d, TsParams P, ASlots sl, RLists lists, int32_t* retry_list, int rank, int world,
-                                               int32_t* owned_list, int class_mask) {
+                                               int32_t* owned_list, int class_mask, int32_t* fb_list, int fb_waves, int fb_cap) {
   AScratch S;
   scratch_bind(sl, blockIdx.x, S);
   RQueue q;
   for (int c = 0; c < 4; c++) { q.l[c] = lists.l[c]; q.n[c] = ((class_mask >> c) & 1) ? d.cnt->replan_n[c] : 0; }
   q.retry_list = retry_list; q.owned_list = owned_list; q.rank = rank; q.world = world;
+  q.fb_list = fb_list; q.fb_waves = fb_waves; q.fb_cap = fb_cap;
   while (uni(replan_turn(d, P, &S, q))) {}
   if (threadIdx.x == 0) sl.slot_epoch[blockIdx.x] = S.epoch;
 }
@@ -1204,11 +1236,22 @@ struct ReplanRec {
   int32_t pad_[3];
 };
 static_assert(sizeof(ReplanRec) == 112, "ReplanRec is exchanged as 28 ints");
-__global__ void k_replan_export(Dev d, const int32_t* owned, int n, ReplanRec* recs, uint32_t* words, unsigned long long* words_n) {
+// `count_only`: add up the words the export will need and touch nothing else (the host sizes the word buffer with it: the
+// pool's growth over the phase is no bound once a garbage collection ran inside it).
+__global__ void k_replan_export(Dev d, const int32_t* owned, int n, ReplanRec* recs, uint32_t* words, unsigned long long* words_n,
+                                int count_only) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const int i = owned[t];
   const int vid = d.active[i];
+  if (count_only) {
+    if (vid < 0) return;
+    const uint8_t chg = d.chg[vid];
+    unsigned long long nw = (chg & 1) ? (unsigned long long)((d.path_len[vid] + 15) >> 4) : 0ull;
+    for (int k = 0; k < 4; k++) if ((chg >> (1 + k)) & 1) nw += (unsigned long long)((d.ax_len[k][vid] + 15) >> 4);
+    if (nw) atomicAdd(words_n, nw);
+    return;
+  }
   ReplanRec r;
   r.i = i; r.vid = vid;
   r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;

@@ -35,10 +35,10 @@
 namespace {
 
 #ifndef TS_QUAD_LCAP
-#define TS_QUAD_LCAP 316
+#define TS_QUAD_LCAP 156
 #endif
 #ifndef TS_QUAD_WAVES_PER_CU
-#define TS_QUAD_WAVES_PER_CU 4
+#define TS_QUAD_WAVES_PER_CU 7
 #endif
 constexpr int QL = TS_QUAD_LCAP;            // heap slots per search in LDS (and the stride between two searches' heaps)
 // (bank spread: the 8-byte slots of the eight quads of a half-wave at the same heap index must fall into different banks)
@@ -47,6 +47,10 @@ static_assert((size_t)16 * QL * 8 * TS_QUAD_WAVES_PER_CU <= 160 * 1024 - 512, "t
 constexpr int QT_LOG_MAX = 10;              // table window: at most 1024 x 1024 cells
 constexpr int Q_CELLS = 4096;               // path buffer capacity per search (cells)
 constexpr int Q_SPILL = 7936;               // heap slots per search beyond LDS (HBM)
+#ifndef TS_QUAD_MAX_EXP
+#define TS_QUAD_MAX_EXP (1 << 17)
+#endif
+constexpr int Q_MAX_EXP = TS_QUAD_MAX_EXP;  // expansions after which a quad hands its search (and vehicle) to k_replan
 constexpr uint32_t Q_DIST_MASK = (1u << 22) - 1, Q_STAMP_SHIFT = 24, Q_DIR_SHIFT = 22;
 enum { QS_NEEDJOB = 0, QS_POLICY = 1, QS_SEARCH = 2, QS_FOUND = 3, QS_EMPTY = 4, QS_ABANDON = 5, QS_IDLE = 6 };
 
@@ -88,7 +92,16 @@ struct QState {
   uint32_t stamp;           // epoch << 24
   int soft;
   int n_exp, n_relax;
+  unsigned long long xpre;  // heap entry hs - 1 when it lies beyond LDS (requested at the end of the previous turn)
+#ifdef TS_QUAD_PROF
+  long long pf[8], pt;
+#endif
 };
+#ifdef TS_QUAD_PROF
+#define QP(k) do { const long long _t = clock64(); s.pf[k] += _t - s.pt; s.pt = _t; } while (0)
+#else
+#define QP(k) do { } while (0)
+#endif
 struct QConst {   // per quad, fixed for the kernel's lifetime
   TS_GLOBAL uint32_t* tab;
   gu64p gq;
@@ -110,6 +123,11 @@ __device__ __forceinline__ uint32_t q_tix(const QConst& K, int x, int y) {
 __device__ __forceinline__ uint32_t q_aix(const QConst& K, int x, int y) {
   return (((__umul24((uint32_t)(y >> 3), (uint32_t)K.W8) + (uint32_t)(x >> 3)) << 6) | (uint32_t)((y & 7) << 3) | (uint32_t)(x & 7));
 }
+// heap slot k of the quad's search: LDS below QL, the search's HBM spill above.  The turn's hot path uses the LDS forms
+// only (no branch around a memory operation, no wait for the expansion's loads in flight); slots that may lie beyond QL
+// are touched in blocks of their own, which only run for quads whose heap has outgrown LDS.
+__device__ __forceinline__ u64 q_lget(const QConst& K, int k) { return q_lds[K.lbase + k]; }
+__device__ __forceinline__ void q_lput(const QConst& K, int k, u64 v) { q_lds[K.lbase + k] = v; }
 __device__ __forceinline__ u64 q_hget(const QConst& K, int k) {
   u64 v;
   if (k < QL) v = q_lds[K.lbase + k]; else v = K.gq[k - QL];
@@ -119,11 +137,43 @@ __device__ __forceinline__ void q_hput(const QConst& K, int k, u64 v) {
   if (k < QL) q_lds[K.lbase + k] = v; else K.gq[k - QL] = v;
 }
 
+// Two levels of heap_sift_down (astar_numba.py:67-85) below the hole at slot p: lanes 0 / 1 of the quad fetch the hole's
+// children (2 / 3 mirror them), the four lanes its four grandchildren; every lane decides with its sibling's key (one DPP
+// swap) whether its entry would move up if its parent were the hole - smallest of (x, left, right), ties to x, then to
+// the left - and one OR over the quad tells every lane the path.  Returns true when x has found its place (p).
+template <bool DEEP>
+__device__ __forceinline__ bool quad_sift2(const QConst& K, int& p, int size, int xf) {
+  const int j = K.j, side = j & 1;
+  const int c = 2 * p + 1 + side, gc = 4 * p + 3 + j;
+  const bool cv = c < size, gv = gc < size;
+  u64 ce = 0, ge = 0;
+  if (cv) ce = DEEP ? q_hget(K, c) : q_lget(K, c);
+  if (gv) ge = DEEP ? q_hget(K, gc) : q_lget(K, gc);
+  const int cf = cv ? hq_f(ce) : 0x7FFFFFFF, gf = gv ? hq_f(ge) : 0x7FFFFFFF;
+  const int csf = qperm<QP_SWAP1>(cf), gsf = qperm<QP_SWAP1>(gf);
+  const unsigned adj = (unsigned)(side ^ 1);
+  const bool cw = (unsigned)cf < min((unsigned)xf, (unsigned)csf + adj);
+  const bool gw = (unsigned)gf < min((unsigned)xf, (unsigned)gsf + adj);
+  const int bits = quad_or((cw ? (1 << j) : 0) | (gw ? (16 << j) : 0));
+  const int w1 = bits & 3;
+  if (w1 == 0) return true;
+  const int sdn = w1 >> 1;                              // the hole moves to the left (0) / right (1) child
+  if (cw & (j < 2)) { if (DEEP) q_hput(K, p, ce); else q_lput(K, p, ce); }
+  const int pc = 2 * p + 1 + sdn;
+  const int w2 = (bits >> (4 + 2 * sdn)) & 3;
+  if (w2 == 0) { p = pc; return true; }
+  const int t = 2 * sdn + (w2 >> 1);                    // ... and on to grandchild t
+  if (j == t) { if (DEEP) q_hput(K, pc, ge); else q_lput(K, pc, ge); }
+  p = 4 * p + 3 + t;
+  return false;
+}
+
 // One turn of astar_core's main loop (astar_numba.py:136-237) for every quad whose search is on.  Returns the quad's
 // new state: QS_SEARCH, QS_FOUND (the goal was popped), QS_EMPTY (heap empty: `return []`) or QS_ABANDON.
 __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
   if (s.hs <= 0) return QS_EMPTY;
   const int j = K.j;
+  QP(7);
   // ---- the direction window follows the heap's end: slots hs - 1 (read by this pop) .. hs + 2 (written by its pushes)
   if (s.hs + 2 > s.wb + 31) {
     K.gdw[s.wb >> 4] = (uint32_t)s.dwin;
@@ -134,10 +184,10 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
     s.dwin = (s.dwin << 32) | (u64)K.gdw[(s.wb >> 4) - 1];
     s.wb -= 16;
   }
-  // ---- pop (138-148)
-  const u64 root = q_lds[K.lbase];
+  // ---- pop (138-148).  The last entry (it takes the root's place) was requested at the end of the previous turn when it
+  // lies beyond LDS
+  const u64 root = q_lget(K, 0);
   const int last_i = s.hs - 1;
-  const u64 x = q_hget(K, last_i);
   const int f_top = hq_f(root);
   const uint32_t cxy = (uint32_t)hq_i(root);
   const int cx = (int)(cxy & 0xFFFFu), cy = (int)(cxy >> 16);
@@ -148,104 +198,115 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
   // the table record of neighbour j, every lane (one request) the popped cell's own
   const int nx = cx + K.dx, ny = cy + K.dy;
   const bool inb = (unsigned)nx < (unsigned)K.W && (unsigned)ny < (unsigned)K.H;
-  const uint32_t a_ix = inb ? q_aix(K, nx, ny) : q_aix(K, cx, cy);
-  const uint32_t t_ix = inb ? q_tix(K, nx, ny) : q_tix(K, cx, cy);
+  const uint32_t a_ixc = q_aix(K, cx, cy), t_ixc = q_tix(K, cx, cy);
+  const uint32_t a_ix = inb ? q_aix(K, nx, ny) : a_ixc;
+  const uint32_t t_ix = inb ? q_tix(K, nx, ny) : t_ixc;
   const u64 am_l = ld8(K.amap, a_ix);
   const uint32_t t_l = K.tab[t_ix];
-  const uint32_t am_c = (uint32_t)ld8(K.amap, q_aix(K, cx, cy));
-  const uint32_t t_c = K.tab[q_tix(K, cx, cy)];
+  const uint32_t am_c = *(const TS_GLOBAL uint32_t*)((const TS_GLOBAL char*)K.amap + (uint32_t)(a_ixc << 3));
+  const uint32_t t_c = K.tab[t_ixc];
+  QP(0);
   if (last_i > 0) {
     s.dir0 = xd;
-    // heap_sift_down (67-85): the last entry sinks from the root
+    const u64 xl = q_lget(K, min(last_i, QL - 1));
+    const u64 x = last_i < QL ? xl : s.xpre;
     const int xf = hq_f(x);
-    const int side = j & 1;          // lanes 0 / 2 look at the left child, 1 / 3 at the right one
     int p = 0;
-    for (;;) {
-      const int c = 2 * p + 1 + side;
-      const bool valid = c < last_i;
-      u64 e = 0;
-      if (valid) e = q_hget(K, c);
-      const int ef = valid ? hq_f(e) : 0x7FFFFFFF;
-      const int sf = qperm<QP_SWAP1>(ef);
-      // smallest of (x, left, right), ties to x, then to left: my entry moves up iff ef < xf and (left: ef <= sf, right: ef < sf)
-      const bool win = (unsigned)ef < min((unsigned)xf, (unsigned)sf + (unsigned)(side ^ 1));
-      const int w = quad_or(win ? (1 << j) : 0) & 3;    // (lanes 2 / 3 mirror 0 / 1)
-      if (w == 0) break;
-      if (win && j < 2) q_hput(K, p, e);
-      p = 2 * p + 1 + (w >> 1);
+    bool done = false;
+    // (a step reads slots up to 4 p + 6: LDS-only code while those that exist all lie below QL)
+    while (!done && (last_i <= QL || 4 * p + 6 < QL)) done = quad_sift2<false>(K, p, last_i, xf);
+    QP(1);
+    if (!done) {
+      do done = quad_sift2<true>(K, p, last_i, xf); while (!done);
     }
     if (j == 0) q_hput(K, p, x);
   }
   wave_mem_sync();
-  if (cxy == s.goal_xy) return QS_FOUND;   // (151: before the staleness test)
-  const int g = f_top - (abs(cx - s.gx) + abs(cy - s.gy));
-  {
-    const int dist_c = ((t_c ^ s.stamp) >> Q_STAMP_SHIFT) == 0u ? (int)(t_c & Q_DIST_MASK) : A_INF;
-    if (g > dist_c) return QS_SEARCH;      // (165)
-  }
-  s.n_exp++;
-  // ---- lane j evaluates neighbour j (171-225) in half units, exactly as astar_loop<HALF> does
-  const uint32_t a_l = (uint32_t)am_l;
-  const bool node_l = (uint32_t)(am_l >> 32) != 0xFFFFFFFFu;
-  const int dist_l = ((t_l ^ s.stamp) >> Q_STAMP_SHIFT) == 0u ? (int)(t_l & Q_DIST_MASK) : A_INF;
-  const bool n_occ = ((a_l >> 8) & 1u) != 0u, n_stop = ((a_l >> 9) & 1u) != 0u, n_road = ((a_l >> 4) & 1u) != 0u;
-  const uint32_t rt = (a_l >> 6) & 3u;
-  const bool flow = ((am_c >> j) & 1u) != 0u;
-  const bool turn = K.turn_on & (prev_dir != -1) & (j != prev_dir);
-  int n2 = 2 * (g + 1);
-  n2 += turn ? K.turn2 : 0;
-  n2 += n_occ ? (int)(a_l >> AMAP_PEN_SHIFT) : 0;
-  n2 += n_stop ? K.stop2 : 0;
-  const int rtp = rt == 1u ? K.rt2_1 : rt == 2u ? K.rt2_2 : rt == 3u ? K.rt2_3 : 0;
-  n2 += (K.rt_on & n_road) ? rtp : 0;
-  const bool ok = inb & node_l & flow & ((s.soft != 0) | !(n_occ | n_stop)) & (n2 < 2 * dist_l);
-  const int ngi = n2 >> 1;
-  // what this searcher cannot carry: a g beyond the record's 22 bits, a cell the table window would alias
-  bool bad = ok & (ngi > (int)Q_DIST_MASK);
-  if (K.chk_x) bad |= ok & (abs(nx - s.sx) >= K.half_w);
-  if (K.chk_y) bad |= ok & (abs(ny - s.sy) >= K.half_h);
-  const int relax = quad_or((ok ? (1 << j) : 0) | (bad ? 16 : 0));
-  if (relax & 16) return QS_ABANDON;
-  if (relax == 0) return QS_SEARCH;
-  const int n_new = __builtin_popcount((unsigned)relax);
-  if (s.hs + n_new > QL + Q_SPILL) return QS_ABANDON;
-  s.n_relax += n_new;
-  if (ok) K.tab[t_ix] = (uint32_t)ngi | ((uint32_t)j << Q_DIR_SHIFT) | s.stamp;   // dist / came_from (226-227)
-  const int nf_l = ngi + abs(nx - s.gx) + abs(ny - s.gy);
-  const int nxy_l = (int)((uint32_t)nx | ((uint32_t)ny << 16));
-  // ---- heap pushes in the reference's order N, E, S, W (229-237)
-  auto push = [&](int dd, int nf, int nxy) {
-    const int i = s.hs;
-    if (i == 0) s.dir0 = dd;
-    else {
-      const int sh = 2 * ((i - s.wb) & 31);
-      s.dwin = (s.dwin & ~(3ull << sh)) | ((u64)(unsigned)dd << sh);
+  QP(2);
+  int st = QS_SEARCH;
+  do {
+    if (cxy == s.goal_xy) { st = QS_FOUND; break; }   // (151: before the staleness test)
+    const int g = f_top - (abs(cx - s.gx) + abs(cy - s.gy));
+    {
+      const int dist_c = ((t_c ^ s.stamp) >> Q_STAMP_SHIFT) == 0u ? (int)(t_c & Q_DIST_MASK) : A_INF;
+      if (g > dist_c) break;      // (165)
     }
-    // heap_sift_up (52-65): the four lanes fetch four ancestors of slot i at a time; ancestor k = ((i + 1) >> k) - 1
-    const int depth = 31 - __builtin_clz((unsigned)(i + 1));
-    int rise = 0;
-    for (int base = 0; base < depth; base += 4) {
-      const int k = base + 1 + j;
-      const bool has = k <= depth;
-      const int a = (int)(((unsigned)(i + 1) >> (k & 31)) - 1u);
-      u64 anc = 0;
-      if (has) anc = q_hget(K, a);
-      const bool up = has & (nf < hq_f(anc));
-      const int um = quad_or(up ? (1 << j) : 0);
-      const int cnt = __builtin_ctz(~(unsigned)um);      // the entry passes a PREFIX of its ancestors (heap order)
-      if (up) q_hput(K, (int)(((unsigned)(i + 1) >> ((k - 1) & 31)) - 1u), anc);   // ancestor k moves to where k - 1 was
-      rise += cnt;
-      if (cnt < 4) break;
+    s.n_exp++;
+    if (s.n_exp > Q_MAX_EXP) { st = QS_ABANDON; break; }   // a long search: k_replan's single search is the faster one
+    QP(3);
+    // ---- lane j evaluates neighbour j (171-225) in half units, exactly as astar_loop<HALF> does
+    const uint32_t a_l = (uint32_t)am_l;
+    const bool node_l = (uint32_t)(am_l >> 32) != 0xFFFFFFFFu;
+    const int dist_l = ((t_l ^ s.stamp) >> Q_STAMP_SHIFT) == 0u ? (int)(t_l & Q_DIST_MASK) : A_INF;
+    const bool n_occ = ((a_l >> 8) & 1u) != 0u, n_stop = ((a_l >> 9) & 1u) != 0u, n_road = ((a_l >> 4) & 1u) != 0u;
+    const uint32_t rt = (a_l >> 6) & 3u;
+    const bool flow = ((am_c >> j) & 1u) != 0u;
+    const bool turn = K.turn_on & (prev_dir != -1) & (j != prev_dir);
+    int n2 = 2 * (g + 1);
+    n2 += turn ? K.turn2 : 0;
+    n2 += n_occ ? (int)(a_l >> AMAP_PEN_SHIFT) : 0;
+    n2 += n_stop ? K.stop2 : 0;
+    const int rtp = rt == 1u ? K.rt2_1 : rt == 2u ? K.rt2_2 : rt == 3u ? K.rt2_3 : 0;
+    n2 += (K.rt_on & n_road) ? rtp : 0;
+    const bool ok = inb & node_l & flow & ((s.soft != 0) | !(n_occ | n_stop)) & (n2 < 2 * dist_l);
+    const int ngi = n2 >> 1;
+    // what this searcher cannot carry: a g beyond the record's 22 bits, a cell the table window would alias
+    bool bad = ok & (ngi > (int)Q_DIST_MASK);
+    if (K.chk_x) bad |= ok & (abs(nx - s.sx) >= K.half_w);
+    if (K.chk_y) bad |= ok & (abs(ny - s.sy) >= K.half_h);
+    int relax = quad_or((ok ? (1 << j) : 0) | (bad ? 16 : 0));
+    if (relax & 16) { st = QS_ABANDON; break; }
+    if (relax == 0) break;
+    const int n_new = __builtin_popcount((unsigned)relax);
+    if (s.hs + n_new > QL + Q_SPILL) { st = QS_ABANDON; break; }
+    s.n_relax += n_new;
+    if (ok) K.tab[t_ix] = (uint32_t)ngi | ((uint32_t)j << Q_DIR_SHIFT) | s.stamp;   // dist / came_from (226-227)
+    const int nf_l = ngi + abs(nx - s.gx) + abs(ny - s.gy);
+    const int nxy_l = (int)((uint32_t)nx | ((uint32_t)ny << 16));
+    const int nf0 = qperm<QP_B0>(nf_l), nf1 = qperm<QP_B1>(nf_l), nf2 = qperm<QP_B2>(nf_l), nf3 = qperm<QP_B3>(nf_l);
+    const int nc0 = qperm<QP_B0>(nxy_l), nc1 = qperm<QP_B1>(nxy_l), nc2 = qperm<QP_B2>(nxy_l), nc3 = qperm<QP_B3>(nxy_l);
+    QP(4);
+    // ---- heap pushes in the reference's order N, E, S, W (229-237)
+    while (relax) {
+      const int dd = __builtin_ctz((unsigned)relax);
+      relax &= relax - 1;
+      const int nf = dd == 0 ? nf0 : dd == 1 ? nf1 : dd == 2 ? nf2 : nf3;
+      const int nxy = dd == 0 ? nc0 : dd == 1 ? nc1 : dd == 2 ? nc2 : nc3;
+      const int i = s.hs;
+      if (i == 0) s.dir0 = dd;
+      else {
+        const int sh = 2 * ((i - s.wb) & 31);
+        s.dwin = (s.dwin & ~(3ull << sh)) | ((u64)(unsigned)dd << sh);
+      }
+      // heap_sift_up (52-65): the four lanes fetch four ancestors of slot i at a time; ancestor k = ((i + 1) >> k) - 1.
+      // (only the parent generation of a slot beyond 2 QL can lie beyond LDS: ancestors 5 and up are below QL for every
+      // heap the spill can hold)
+      const int depth = 31 - __builtin_clz((unsigned)(i + 1));
+      int rise = 0;
+      for (int base = 0; base < depth; base += 4) {
+        const int k = base + 1 + j;
+        const bool has = k <= depth;
+        const int a = (int)(((unsigned)(i + 1) >> (k & 31)) - 1u);
+        u64 anc = 0;
+        if (base == 0 && i > 2 * QL) { if (has) anc = q_hget(K, a); }
+        else if (has) anc = q_lget(K, a);
+        const bool up = has & (nf < hq_f(anc));
+        const int um = quad_or(up ? (1 << j) : 0);
+        const int cnt = __builtin_ctz(~(unsigned)um);      // the entry passes a PREFIX of its ancestors (heap order)
+        if (up) q_hput(K, (int)(((unsigned)(i + 1) >> ((k - 1) & 31)) - 1u), anc);   // ancestor k moves to where k - 1 was
+        rise += cnt;
+        if (cnt < 4) break;
+      }
+      if (j == 0) q_hput(K, (int)(((unsigned)(i + 1) >> (rise & 31)) - 1u), hq_pack(nf, nxy));
+      s.hs = i + 1;
+      wave_mem_sync();
     }
-    if (j == 0) q_hput(K, (int)(((unsigned)(i + 1) >> (rise & 31)) - 1u), hq_pack(nf, nxy));
-    s.hs = i + 1;
-    wave_mem_sync();
-  };
-  if (relax & 1) push(0, qperm<QP_B0>(nf_l), qperm<QP_B0>(nxy_l));
-  if (relax & 2) push(1, qperm<QP_B1>(nf_l), qperm<QP_B1>(nxy_l));
-  if (relax & 4) push(2, qperm<QP_B2>(nf_l), qperm<QP_B2>(nxy_l));
-  if (relax & 8) push(3, qperm<QP_B3>(nf_l), qperm<QP_B3>(nxy_l));
-  return QS_SEARCH;
+  } while (0);
+  QP(5);
+  // the entry the next pop moves to the root, if it lies beyond LDS: on its way while this turn ends and the next begins
+  if (st == QS_SEARCH && s.hs - 1 >= QL) s.xpre = K.gq[s.hs - 1 - QL];
+  QP(6);
+  return st;
 }
 
 struct QReq { int start, goal, soft, cap; int32_t* out; };
@@ -284,7 +345,7 @@ __device__ __attribute__((noinline)) int quad_policy(const Dev& d, const TsParam
       atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
       if (q.owned_list) q.owned_list[atomicAdd(&d.cnt->replan_n[6], 1)] = i;
     } else if (r == DV_POOL_FULL) q.retry_list[atomicAdd(&d.cnt->replan_n[4], 1)] = i;
-    else q.fallback_list[atomicAdd(&d.cnt->quad_n[0], 1)] = i;     // DV_BAIL, DV_OVERFLOW: k_replan takes the vehicle
+    else __hip_atomic_store(&q.fallback_list[atomicAdd(&d.cnt->quad_n[0], 1)], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // DV_BAIL, DV_OVERFLOW: k_replan takes the vehicle
   }
   return r;
 }
@@ -318,10 +379,15 @@ __global__ void __launch_bounds__(64) k_replan_quad(Dev d, TsParams P, QSlots qs
   K.rt2_3 = (int)((double)P.road_type_penalty_r3 * 2.0);
   uint32_t epoch = qs.slot_epoch[slot];
   QState s;
-  s.hs = 0; s.dir0 = -1; s.wb = 0; s.dwin = 0; s.gx = s.gy = s.sx = s.sy = 0; s.goal_xy = 0; s.stamp = 0; s.soft = 0; s.n_exp = 0; s.n_relax = 0;
+  s.hs = 0; s.dir0 = -1; s.wb = 0; s.dwin = 0; s.xpre = 0; s.gx = s.gy = s.sx = s.sy = 0; s.goal_xy = 0; s.stamp = 0; s.soft = 0; s.n_exp = 0; s.n_relax = 0;
   QReq req;
   req.start = req.goal = req.soft = req.cap = 0; req.out = nullptr;
   int st = QS_NEEDJOB, job = -1, n_done = 0;
+#ifdef TS_QUAD_PROF
+  long long pf_t0 = clock64(), pf_search = 0, pf_turns = 0, pf_quadturns = 0;
+  for (int k = 0; k < 8; k++) s.pf[k] = 0;
+  s.pt = clock64();
+#endif
   for (;;) {
     // ---------------- per quad: everything that is not a search turn ----------------
     while (st != QS_SEARCH && st != QS_IDLE) {
@@ -359,7 +425,7 @@ __global__ void __launch_bounds__(64) k_replan_quad(Dev d, TsParams P, QSlots qs
         }
       }
       if (st == QS_ABANDON) {
-        if (one) fallback_list[atomicAdd(&d.cnt->quad_n[0], 1)] = job;
+        if (one) __hip_atomic_store(&fallback_list[atomicAdd(&d.cnt->quad_n[0], 1)], job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         st = QS_NEEDJOB;
       }
       if (st == QS_NEEDJOB) {
@@ -407,11 +473,32 @@ __global__ void __launch_bounds__(64) k_replan_quad(Dev d, TsParams P, QSlots qs
     const unsigned long long act = ballot(st == QS_SEARCH);
     if (act == 0ull) break;
     // ---------------- the searches of the wave advance in lockstep until one of them ends ----------------
+#ifdef TS_QUAD_PROF
+    const long long pf_a = clock64();
+#endif
     do {
+#ifdef TS_QUAD_PROF
+      pf_turns++; pf_quadturns += __builtin_popcountll(act) >> 2;
+#endif
       if (st == QS_SEARCH) st = quad_turn(K, s);
     } while (ballot(st == QS_SEARCH) == act);
+#ifdef TS_QUAD_PROF
+    pf_search += clock64() - pf_a;
+#endif
   }
+#ifdef TS_QUAD_PROF
+  if (lane == 0) {   // wave cycles in all / in the lockstep loop, turns of the wave, quad-turns
+    atomicAdd((unsigned long long*)&d.cnt->prof[0], (unsigned long long)(clock64() - pf_t0));
+    atomicAdd((unsigned long long*)&d.cnt->prof[1], (unsigned long long)pf_search);
+    atomicAdd((unsigned long long*)&d.cnt->prof[2], (unsigned long long)pf_turns);
+    atomicAdd((unsigned long long*)&d.cnt->prof[3], (unsigned long long)pf_quadturns);
+    for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&d.cnt->qprof[k], (unsigned long long)s.pf[k]);
+  }
+#endif
   if (one) qs.slot_epoch[slot] = epoch;
+  // every hand-back of this wave is published before the wave counts itself out (k_replan's replan_turn waits on both)
+  __threadfence();
+  if (lane == 0) atomicAdd(&d.cnt->quad_n[3], 1);
 }
 
 }  // namespace

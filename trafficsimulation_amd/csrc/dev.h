@@ -45,6 +45,7 @@ struct DevCnt {
   unsigned int rng_event;   // first (vehicle index * 2 + is_collision) whose draw fired this pass, 0xFFFFFFFF = none
   unsigned int rng_tot[2];  // pass 1 totals: fixed words, number of speed rolls
   int dec_arrived; // 1 + decide index of the vehicle that despawned inside this stretch of the decide phase (0 = none)
+  long long qprof[8];  // TS_QUAD_PROF builds: cycles per segment of k_replan_quad's turn (lane 0 of every wave)
   long long prof[8];   // TS_KPROF builds: cycles per segment of the last search's loop
   int dbg[8];      // debugging aid: first watchdog that fired inside a replanning kernel (code, vehicle index, values)
 };

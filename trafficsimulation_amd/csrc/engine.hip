@@ -96,29 +96,37 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     HIPOK(hipcub::DeviceRadixSort::SortPairs(e->sort_tmp, tmp_bytes, e->sort_keys, e->sort_keys_alt, e->replan_list[h], e->sort_vals_alt, n, 0, REPLAN_KEY_BITS, st));
     HIPOK(hipMemcpyAsync(e->replan_list[h], e->sort_vals_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
   }
-  // First pass, when the parameters allow the quad searcher: the classes below QUAD_CLASS_MASK's top go to k_replan_quad
-  // (sixteen searches per wave, on its own stream), the most expensive class to k_replan beside it (its searches are the
-  // tick's tail and want the faster single search); what the quads hand back, and what found the pool full, is queued again
-  // for k_replan below.
-  if (e->quad_on && replan_pending(e->hint + 8) > 0) {
-    static const int quad_mask = getenv("TS_QUAD_CLASSES") ? atoi(getenv("TS_QUAD_CLASSES")) & 15 : 7;
+  // The quad searcher (astar_quad.h; opt-in with TS_QUAD=1, see DESIGN.md section 4c for why it is not the default): a big
+  // queue (a replanning wave of TS_QUAD_MIN entries or more) sends the classes in TS_QUAD_CLASSES to k_replan_quad (sixteen
+  // searches per wave, on its own stream) while k_replan runs beside it on the most expensive class and on every vehicle
+  // the quads hand back as they work (searches that outgrow their window, heap or expansion budget, step-limited ones).
+  // Smaller queues are bounded by their longest search, and that one is faster alone on a wave.
+  const int quad_min = getenv("TS_QUAD_MIN") ? atoi(getenv("TS_QUAD_MIN")) : 65536;
+  if (e->quad_on && replan_pending(e->hint + 8) >= std::max(quad_min, 1)) {
+    const int quad_mask = getenv("TS_QUAD_CLASSES") ? atoi(getenv("TS_QUAD_CLASSES")) & 15 : 7;
     int nq = 0, nw = 0;
     for (int c = 0; c < 4; c++) { if ((quad_mask >> c) & 1) nq += e->hint[8 + c]; else nw += e->hint[8 + c]; }
     const double tl = now_ms();
     HIPOK(hipMemsetAsync(d.cnt->quad_n, 0, sizeof(int) * 4, st));
     int tok = prof_begin(e, PK_REPLAN, nq + nw);
+    int qgrid = 0;
     if (nq > 0) {
+      HIPOK(hipMemsetAsync(e->replan_list[5], 0xFF, (size_t)nq * 4, st));     // (hand-back entries: -1 = not written yet)
       HIPOK(hipEventRecord(e->quad_ev0, st));
       HIPOK(hipStreamWaitEvent(e->quad_stream, e->quad_ev0, 0));
-      const int grid = std::min((nq + 15) / 16, e->qslots.n_slots / 16);
-      if (g_trace_launches) { fprintf(stderr, "[launch] k_replan_quad items=%d grid=%d\n", nq, grid); fflush(stderr); }
-      hipLaunchKernelGGL(k_replan_quad, dim3(grid), dim3(64), 0, e->quad_stream, d, P, e->qslots, rl, quad_mask, e->replan_list[4],
+      qgrid = std::min((nq + 15) / 16, e->qslots.n_slots / 16);
+      if (g_trace_launches) { fprintf(stderr, "[launch] k_replan_quad items=%d grid=%d\n", nq, qgrid); fflush(stderr); }
+      hipLaunchKernelGGL(k_replan_quad, dim3(qgrid), dim3(64), 0, e->quad_stream, d, P, e->qslots, rl, quad_mask, e->replan_list[4],
                          e->replan_list[5], e->dist_rank, e->dist_world, e->dist_world > 1 ? e->owned_list : nullptr);
       HIPOK(hipEventRecord(e->quad_ev1, e->quad_stream));
     }
-    if (nw > 0)
-      hipLaunchKernelGGL(k_replan, dim3(std::min(nw, e->slots.n_slots)), dim3(64), 0, st, d, P, e->slots, rl, e->replan_list[4], e->dist_rank,
-                         e->dist_world, e->dist_world > 1 ? e->owned_list : nullptr, 15 & ~quad_mask);
+    // (k_replan never holds anything the quads wait for: were the two launches ever serialised, it would simply find the
+    // hand-back list complete)
+    const int side_waves = getenv("TS_QUAD_SIDE_WAVES") ? atoi(getenv("TS_QUAD_SIDE_WAVES")) : 512;
+    const int wgrid = std::min(e->slots.n_slots, std::max(std::min(nw, e->slots.n_slots), nq > 0 ? side_waves : 1));
+    if (nw > 0 || nq > 0)
+      hipLaunchKernelGGL(k_replan, dim3(wgrid), dim3(64), 0, st, d, P, e->slots, rl, e->replan_list[4], e->dist_rank,
+                         e->dist_world, e->dist_world > 1 ? e->owned_list : nullptr, 15 & ~quad_mask, e->replan_list[5], qgrid, nq);
     if (nq > 0) HIPOK(hipStreamWaitEvent(st, e->quad_ev1, 0));
     prof_end(e, tok);
     int qn[4] = {0, 0, 0, 0};
@@ -126,31 +134,45 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     HIPOK(hipMemcpyAsync(e->hint + 3, &d.cnt->error, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPOK(hipMemcpyAsync(qn, d.cnt->quad_n, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
-    if (g_trace_launches) { fprintf(stderr, "[done] first replanning pass\n"); fflush(stderr); }
+    if (g_trace_launches) { fprintf(stderr, "[done] replanning pass with the quads\n"); fflush(stderr); }
     if (e->hint[3] == TS_E_CAPACITY) return fail(e, TS_E_CAPACITY, "an A* search exceeded its heap or path buffers");
     const int fb = qn[0], retry = e->hint[8 + 4];
     e->quad_jobs += nq; e->quad_fallbacks += fb;
+#ifdef TS_QUAD_PROF
+    {
+      long long pf[8];
+      HIPOK(hipMemcpy(pf, d.cnt->prof, sizeof(pf), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[quadprof] wave cycles %lld, in the lockstep loop %lld, wave turns %lld, quad turns %lld: %.0f cycles per turn, %.1f quads per turn\n",
+              pf[0], pf[1], pf[2], pf[3], pf[2] ? (double)pf[1] / (double)pf[2] : 0.0, pf[2] ? (double)pf[3] / (double)pf[2] : 0.0);
+      HIPOK(hipMemset(d.cnt->prof, 0, sizeof(pf)));
+      long long qp[8];
+      HIPOK(hipMemcpy(qp, d.cnt->qprof, sizeof(qp), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[quadprof] per wave turn: pop+loads %.0f, sift LDS %.0f, sift deep %.0f, goal/stale %.0f, eval %.0f, pushes(+skipped) %.0f, tail %.0f, between turns %.0f\n",
+              (double)qp[0] / pf[2], (double)qp[1] / pf[2], (double)qp[2] / pf[2], (double)qp[3] / pf[2], (double)qp[4] / pf[2], (double)qp[5] / pf[2], (double)qp[6] / pf[2], (double)qp[7] / pf[2]);
+      HIPOK(hipMemset(d.cnt->qprof, 0, sizeof(qp)));
+    }
+#endif
     if (getenv("TS_DEBUG_REPLAN"))
-      fprintf(stderr, "[replan] tick %lld: %d entries to the quads (%d slots), %d to k_replan; handed back %d, pool-full %d, %.2f ms\n",
-              (long long)e->C.step_count, nq, e->qslots.n_slots, nw, fb, retry, now_ms() - tl);
+      fprintf(stderr, "[replan] tick %lld: %d entries to the quads (%d waves of %d), %d to k_replan (%d waves); handed over %d, pool-full %d, %.2f ms\n",
+              (long long)e->C.step_count, nq, qgrid, e->qslots.n_slots / 16, nw, wgrid, fb, retry, now_ms() - tl);
+    if (qn[2] < fb) return fail(e, TS_E_DEVICE, "hand-back entries of the quad searcher were left unserved (internal error)");
+    // what found the path pool full is queued again below
     if (retry > 0) {
       d.pool_cap_words = e->pool_cap;
       rc = pool_make_room(e, (size_t)retry * 1024 + (1u << 20));
       if (rc) return rc;
+      HIPOK(hipMemcpyAsync(e->replan_list[0], e->replan_list[4], (size_t)retry * 4, hipMemcpyDeviceToDevice, st));
     }
-    // the second pass' queue: list 0 = handed-back entries, then the pool-full ones
-    if (fb > 0) HIPOK(hipMemcpyAsync(e->replan_list[0], e->replan_list[5], (size_t)fb * 4, hipMemcpyDeviceToDevice, st));
-    if (retry > 0) HIPOK(hipMemcpyAsync(e->replan_list[0] + fb, e->replan_list[4], (size_t)retry * 4, hipMemcpyDeviceToDevice, st));
     const int keep_owned = e->hint[8 + 6];
     for (int q = 0; q < 8; q++) e->hint[8 + q] = 0;
-    e->hint[8] = fb + retry; e->hint[8 + 6] = keep_owned;
+    e->hint[8] = retry; e->hint[8 + 6] = keep_owned;
     HIPOK(hipMemcpyAsync(d.cnt->replan_n, e->hint + 8, sizeof(int) * 8, hipMemcpyHostToDevice, st));
   }
   while (replan_pending(e->hint + 8) > 0) {
     const int n = replan_pending(e->hint + 8);
     const int grid = std::min(n, e->slots.n_slots);
     LAUNCH(e, PK_REPLAN, n, k_replan, dim3(grid), dim3(64), d, P, e->slots, rl, e->replan_list[4], e->dist_rank, e->dist_world,
-           e->dist_world > 1 ? e->owned_list : nullptr, 15);
+           e->dist_world > 1 ? e->owned_list : nullptr, 15, (int32_t*)nullptr, 0, 0);
     const double tl = now_ms();
     HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
     HIPOK(hipMemcpyAsync(e->hint + 3, &d.cnt->error, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -184,10 +206,25 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
 // Replicated-state multi-GPU mode: after this rank's share of the replans, trade results with the other ranks.
 // `before` = the device counters as they were when the replanning phase began.
 struct XHeader { int64_t n_recs, n_words, n_arr, error; int64_t delta[16]; double ddelta[2]; };
-int exchange_replans(E* e, const DevCnt& before) {
+// `local_rc` != 0: this rank failed on the host side before the exchange (capacity, a device error): it still joins the
+// collective, with a header that says so, and every rank fails the tick together instead of waiting in the all-gather
+// until the process group times out.
+int exchange_replans(E* e, const DevCnt& before, int local_rc) {
   Dev& d = e->d;
   hipStream_t st = e->stream;
   const double t0 = now_ms();
+  if (local_rc) {
+    XHeader hd;
+    memset(&hd, 0, sizeof(hd));
+    hd.delta[14] = local_rc;
+    e->send_buf.resize(sizeof(hd));
+    memcpy(e->send_buf.data(), &hd, sizeof(hd));
+    void* recv = nullptr;
+    int64_t* sizes = nullptr;
+    int64_t stride = 0;
+    (void)e->dist_fn(e->dist_user, e->send_buf.data(), (int64_t)sizeof(hd), &recv, &sizes, &stride);
+    return local_rc;
+  }
   const int n_owned = e->hint[8 + 6];
   if ((size_t)std::max(n_owned, 1) > e->cap_recs) {
     const size_t nc = (size_t)n_owned * 2 + 1024;
@@ -195,23 +232,28 @@ int exchange_replans(E* e, const DevCnt& before) {
     e->cap_recs = nc;
   }
   if (!e->d_xwords_n) HIPOK(dalloc(e, &e->d_xwords_n, 1));
-  // the words this rank's replans wrote are the pool's growth since the phase began (an upper bound for the export)
+  // the words this rank's replans rewrote, counted first (the pool's growth over the phase is no bound: pool_make_room may
+  // have garbage-collected inside it), then exported into a buffer that holds them
   HIPOK(hipMemcpyAsync(e->hcnt, d.cnt, sizeof(DevCnt), hipMemcpyDeviceToHost, st));
+  HIPOK(hipMemsetAsync(e->d_xwords_n, 0, sizeof(unsigned long long), st));
+  if (n_owned > 0)
+    hipLaunchKernelGGL(k_replan_export, dim3(nblk(n_owned)), dim3(BLK), 0, st, d, e->owned_list, n_owned, e->d_recs, e->d_xwords, e->d_xwords_n, 1);
+  unsigned long long need_words = 0;
+  HIPOK(hipMemcpyAsync(&need_words, e->d_xwords_n, sizeof(need_words), hipMemcpyDeviceToHost, st));
   HIPOK(hipStreamSynchronize(st));
   const DevCnt after = *e->hcnt;
-  const size_t grown = (size_t)(after.pool_used >= before.pool_used ? after.pool_used - before.pool_used : after.pool_used) + 16;
-  if (grown > e->cap_xwords) {
-    const size_t nc = grown * 2 + 4096;
+  if ((size_t)need_words + 16 > e->cap_xwords) {
+    const size_t nc = (size_t)need_words * 2 + 4096;
     int rc = regrow(e, &e->d_xwords, 0, nc); if (rc) return rc;
     e->cap_xwords = nc;
   }
   HIPOK(hipMemsetAsync(e->d_xwords_n, 0, sizeof(unsigned long long), st));
   if (n_owned > 0)
-    hipLaunchKernelGGL(k_replan_export, dim3(nblk(n_owned)), dim3(BLK), 0, st, d, e->owned_list, n_owned, e->d_recs, e->d_xwords, e->d_xwords_n);
+    hipLaunchKernelGGL(k_replan_export, dim3(nblk(n_owned)), dim3(BLK), 0, st, d, e->owned_list, n_owned, e->d_recs, e->d_xwords, e->d_xwords_n, 0);
   unsigned long long n_words = 0;
   HIPOK(hipMemcpyAsync(&n_words, e->d_xwords_n, sizeof(n_words), hipMemcpyDeviceToHost, st));
   HIPOK(hipStreamSynchronize(st));
-  if (n_words > e->cap_xwords) return fail(e, TS_E_DEVICE, "replan export overran its word buffer (internal error)");
+  if (n_words != need_words) return fail(e, TS_E_DEVICE, "replan export wrote a different number of words than it counted (internal error)");
   const int n_arr = after.arr_n - before.arr_n;
   XHeader hd;
   memset(&hd, 0, sizeof(hd));
@@ -248,6 +290,7 @@ int exchange_replans(E* e, const DevCnt& before) {
     if ((size_t)sizes[r] < sizeof(XHeader)) return fail(e, TS_E_DEVICE, "short replan exchange buffer");
     XHeader h2;
     memcpy(&h2, q, sizeof(h2));
+    if (h2.delta[14]) return fail(e, (int)h2.delta[14], "rank " + std::to_string(r) + " failed in its share of the replans (error " + std::to_string((long long)h2.delta[14]) + ")");
     in_words += h2.n_words; in_arr += h2.n_arr;
     if ((size_t)sizes[r] != sizeof(XHeader) + (size_t)h2.n_recs * sizeof(ReplanRec) + (size_t)h2.n_words * 4 + (size_t)h2.n_arr * 12)
       return fail(e, TS_E_DEVICE, "replan exchange buffer size mismatch");
@@ -575,9 +618,10 @@ int tick(E* e) {
       HIPOK(hipStreamSynchronize(st));
       const DevCnt before = *e->hcnt;
       const int n_all = replan_pending(e->hint + 8);
-      if (n_all > e->cap_owned) { const int nc = n_all * 2 + 1024; int rc = regrow(e, &e->owned_list, 0, (size_t)nc); if (rc) return rc; e->cap_owned = nc; }
-      if (n_all > 0) { int rc = run_replans(e); if (rc) return rc; }
-      int rc = exchange_replans(e, before);
+      int rc_local = TS_OK;
+      if (n_all > e->cap_owned) { const int nc = n_all * 2 + 1024; rc_local = regrow(e, &e->owned_list, 0, (size_t)nc); if (!rc_local) e->cap_owned = nc; }
+      if (!rc_local && n_all > 0) rc_local = run_replans(e);
+      int rc = exchange_replans(e, before, rc_local);
       if (rc) return rc;
     } else if (replan_pending(e->hint + 8) > 0) { int rc = run_replans(e); if (rc) return rc; }
     return TS_OK;
@@ -1521,15 +1565,16 @@ int ts_add_vehicles_dirs(ts_handle e, int32_t n, const int32_t* start_xy, const 
   return add_vehicles_any(e, n, start_xy, goal_xy, population_type, nullptr, nullptr, path_off, path_dirs);
 }
 
-int ts_remove_vehicle(ts_handle e, int32_t spawn_idx) {
+int ts_remove_vehicle(ts_handle e, int32_t spawn_idx, int32_t population_type) {
   if (!e) return TS_E_INVALID;
+  if (population_type != TS_POP_INTERNAL && population_type != TS_POP_THROUGH) population_type = TS_POP_UNDEFINED;
   if (spawn_idx < 0 || spawn_idx >= e->n_vehicles_total) return fail(e, TS_E_INVALID, "no such live vehicle");
   Dev& d = e->d;
   uint16_t fl = 0;
   HIPOK(hipMemcpy(&fl, d.flags + spawn_idx, 2, hipMemcpyDeviceToHost));
   if (!(fl & VF_ALIVE)) return fail(e, TS_E_INVALID, "no such live vehicle");
   if (fl & VF_SVC) return fail(e, TS_E_UNSUPPORTED, "service vehicles cannot be removed by the host");
-  hipLaunchKernelGGL(k_remove_one, dim3(1), dim3(64), 0, e->stream, d, spawn_idx);
+  hipLaunchKernelGGL(k_remove_one, dim3(1), dim3(64), 0, e->stream, d, spawn_idx, (int)population_type);
   // the lists close up at once (the reference's list.remove / schedule.remove): the next tick shuffles the live keys
   int na = 0, ns = 0;
   int rc = compact(e, 0, e->n_active, &na); if (rc) return rc;

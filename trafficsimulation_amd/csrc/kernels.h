@@ -197,13 +197,14 @@ __device__ __forceinline__ void cell_append(const Dev& d, int cell, int vid) {
 }
 
 // CityModel.remove_vehicle (city_model.py:1920-1941): off the maps, the cell list, the schedule and the decide order
-__device__ __forceinline__ void remove_vehicle_dev(const Dev& d, int vid, int s, int pos, uint16_t& f, int key) {
+// (pop_arg: the population_type argument of CityModel.remove_vehicle; the vehicle's own despawn passes its own, -1 here)
+__device__ __forceinline__ void remove_vehicle_dev(const Dev& d, int vid, int s, int pos, uint16_t& f, int key, int pop_arg = -1) {
   set_occ(d, pos, 0); d.cell[pos].stuck = 0;
   cell_unlink(d, pos, vid);
   f &= ~VF_ALIVE;
   d.sched_kind[s] = K_DEAD;
   d.active[d.active_idx[vid]] = -1;
-  int pop = d.pop[vid];
+  int pop = pop_arg >= 0 ? pop_arg : d.pop[vid];
   if (pop == TS_POP_INTERNAL) atomicAdd((unsigned long long*)&d.cnt->live_internal, (unsigned long long)-1LL);
   else if (pop == TS_POP_THROUGH) atomicAdd((unsigned long long*)&d.cnt->live_through, (unsigned long long)-1LL);
   atomicAdd(&d.cnt->deaths, 1);
@@ -881,10 +882,10 @@ __global__ void k_decide_despawn(Dev d, TsParams P, int i_arrived, int i_skipped
   }
 }
 // CityModel.remove_vehicle called by the host between ticks (ts_remove_vehicle)
-__global__ void k_remove_one(Dev d, int vid) {
+__global__ void k_remove_one(Dev d, int vid, int pop_arg) {
   if (threadIdx.x || blockIdx.x) return;
   uint16_t f = d.flags[vid];
-  remove_vehicle_dev(d, vid, d.sched_slot[vid], d.pos[vid], f, 0);
+  remove_vehicle_dev(d, vid, d.sched_slot[vid], d.pos[vid], f, 0, pop_arg);
   d.flags[vid] = f;
 }
 // (schedule slot, rank) of CityBlocks (which = 0, ids = block index) or vehicles (which = 1, ids = vehicle id)

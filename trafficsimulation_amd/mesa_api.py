@@ -868,8 +868,9 @@ class CityModel:
 
     def remove_vehicle(self, vehicle, population_type: str = "undefined", vehicle_type: str = "undefined"):
         """city_model.py:1920-1941 - between ticks: the vehicle leaves the grid, the schedule and the decide order
-        (the engine knows its population, the two string arguments are accepted for signature compatibility)."""
-        self.engine.remove_vehicle(vehicle._spawn_idx)
+        As in the reference the live counters follow `population_type` as the caller passes it ('internal' / 'through'; the
+        default 'undefined' leaves them alone); `vehicle_type` only concerns service vehicles, which the host cannot remove."""
+        self.engine.remove_vehicle(vehicle._spawn_idx, capi.POP.get(population_type, capi.POP["undefined"]))
         self._vehicles.pop(vehicle._spawn_idx, None)
         self._invalidate()
 

@@ -57,7 +57,12 @@ def astar_hip(width: int, height: int, start_x: int, start_y: int, goal_x: int, 
               density_map: Optional[np.ndarray] = None, soft_obstacles: bool = False, ignore_flow: bool = False,
               maximum_steps: int = 0x7FFFFFFF, _engine_factory: Optional[Callable] = None) -> List[Tuple[int, int]]:
     """astar_numba(width, height, sx, sy, gx, gy, occupancy_map, stop_map, is_road_map, road_type_map,
-    allowed_dirs_map, respect_awareness, awareness_range, density_map, soft_obstacles, ignore_flow, maximum_steps)."""
+    allowed_dirs_map, respect_awareness, awareness_range, density_map, soft_obstacles, ignore_flow, maximum_steps).
+
+    One limit the reference's operator does not have: a `maximum_steps` that can actually bind must not exceed 4094 (the
+    device table keeps the step count of a search node in 12 bits).  A limit of width * height or more never binds (no chain
+    of relaxations revisits a cell) and is accepted, as is the default 0x7FFFFFFF; a value in between raises EngineError
+    (TS_E_UNSUPPORTED) - it is never silently clipped.  The reference's own callers pass 6, 20 or nothing."""
     api = _engine_for(width, height, is_road_map, road_type_map, allowed_dirs_map, awareness_range, _engine_factory, respect_awareness)
     api.debug_set_occupancy(occupancy_map)          # the dynamic planes as the caller sees them right now
     api.upload_map(capi.MAP_STOP, stop_map)
