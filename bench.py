@@ -222,6 +222,9 @@ def main():
     from trafficsimulation_amd import dist as tdist
     seed = args.seed + (1000 * rank if (world > 1 and mode == "replicas") else 0)
     tables, routes, gen_t = make_workload(args.size, args.vehicles, seed, args.world)
+    _rl = np.diff(np.asarray(routes[2], dtype=np.int64))      # cells per initial route (routes = starts, goals, offsets, directions)
+    route_stats = ({"min": int(_rl.min()), "median": float(np.median(_rl)), "mean": float(_rl.mean()), "max": int(_rl.max()),
+                    "kind": "random walks along the flow; the goal is where the walk ends"} if len(_rl) else None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -292,14 +295,35 @@ def main():
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         # HBM traffic per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs of this very
         # command: FETCH_SIZE, WRITE_SIZE in KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        # (only when that profile is of THIS command - size, vehicles, policy, steps and warm-up alike; otherwise null)
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
         if os.path.exists(pmc_path):
             pj = json.load(open(pmc_path))
             pname = {"k_decide_replan": "k_replan"}.get(dom, dom)     # (the profile slot keeps the round-1 name of the kernel family)
-            if pj.get("command_config") == [args.size, args.vehicles, args.policy] and pname in pj.get("kernels", {}):
+            if pj.get("command_config") == [args.size, args.vehicles, args.policy, args.steps, args.warmup] and pname in pj.get("kernels", {}):
                 pk = pj["kernels"][pname]
                 traffic = (2.0 * pk["fetch_kb_avg"] + pk["write_kb_avg"]) * 1024.0
+        # Second roofline for the replanning kernel: instruction issue.  Instructions per expansion come from the SQ counter
+        # passes committed under profiles/ (rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU ... on this build at this size),
+        # the expansion rate is this run's own.  Peaks (MI355X_MICROARCH.md, Execution model): a SIMD issues one wave64 vector
+        # instruction every 2 cycles -> 256 CUs x 4 SIMDs x 2.4 GHz / 2; one scalar unit per CU, one instruction per cycle.
+        issue = None
+        sq_path = os.path.join(ROOT, "profiles", "r03_sq_replan_4096.json")
+        if dom == "k_decide_replan" and os.path.exists(sq_path):
+            sq = json.load(open(sq_path)).get("k_replan", {}).get("per_expansion")
+            if sq:
+                rate = unit_note["expansions_per_s_in_kernel"]
+                valu_peak, salu_peak = 256 * 4 * 2.4e9 / 2, 256 * 2.4e9
+                fv, fs = sq["SQ_INSTS_VALU"] * rate / valu_peak, sq["SQ_INSTS_SALU"] * rate / salu_peak
+                issue = {"bound": "salu" if fs >= fv else "valu", "kernel": dom, "unit": "Ginstr/s",
+                         "achieved": (sq["SQ_INSTS_SALU"] if fs >= fv else sq["SQ_INSTS_VALU"]) * rate / 1e9,
+                         "peak": (salu_peak if fs >= fv else valu_peak) / 1e9, "frac": max(fv, fs),
+                         "valu": {"per_expansion": sq["SQ_INSTS_VALU"], "achieved": sq["SQ_INSTS_VALU"] * rate / 1e9, "peak": valu_peak / 1e9, "frac": fv},
+                         "salu": {"per_expansion": sq["SQ_INSTS_SALU"], "achieved": sq["SQ_INSTS_SALU"] * rate / 1e9, "peak": salu_peak / 1e9, "frac": fs},
+                         "lds_per_expansion": sq.get("SQ_INSTS_LDS"), "vmem_per_expansion": sq.get("SQ_INSTS_VMEM_RD", 0) + sq.get("SQ_INSTS_VMEM_WR", 0),
+                         "source": "profiles/r03_sq_replan_4096.json (instructions per expansion) x this run's expansions/s; "
+                                   "peaks: 1 vector instruction / 2 cycles / SIMD, 1 scalar instruction / cycle / CU at 2.4 GHz"}
         host_keys = [k for k in prof if k.startswith("host_")]
         out = {
             "metric": "agent_steps_per_sec", "value": steps_done / elapsed, "unit": "agent-steps/s",
@@ -313,7 +337,11 @@ def main():
                             + f", {POLICY_TEXT[args.policy]}; random-walk initial routes",
                 "policy": args.policy,
                 "astar": {"calls": calls, "expansions": exp, "relaxations": rel, "rng_fixups": c1.rng_fixups - c0.rng_fixups,
-                          "expansions_per_s": exp / elapsed},
+                          "expansions_per_s": exp / elapsed, "expansions_per_search": exp / max(calls, 1)},
+                # (under the default policy the cost of a replan grows with the square of the distance to the target: the
+                # trip lengths the bench drives ARE its expansions per tick - SURVEY 8(d)'s exit-block goals would be ~10^6
+                # expansions per search)
+                "initial_route_cells": route_stats,
                 "grid": args.size, "vehicles": v0, "live_vehicles_end": live_end,
                 "light_groups": int(len(tables["g_light_off"]) - 1),
                 "multi_gpu_mode": ("single GPU" if world == 1 else
@@ -329,6 +357,7 @@ def main():
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": avg_launch_s * 1e6,
                 "launches": launches}, **unit_note),
+            "roofline_issue": issue,
             "kernels_ms_per_tick": {k: v[0] / args.steps for k, v in prof.items() if not k.startswith("host_")},
             "host_ms_per_tick": {k: prof[k][0] / args.steps for k in host_keys},
             "setup_seconds": {"world": gen_t[0], "routes": gen_t[1]},
@@ -372,6 +401,10 @@ def main():
                           + ("" if cpu_proc.returncode == 0 else "; the child was ended inside the next tick (a replanning wave on one core)"),
                 "ms_per_tick": last["seconds"] / last["ticks"] * 1e3, "ticks": last["ticks"],
                 "astar_expansions_per_s": last["astar_expansions"] / last["seconds"],
+                # the same unit on both legs (expansions of the same algorithm per second of stepping); still different ticks
+                # of the run - the CPU leg never reaches the first replanning wave inside its budget
+                "gpu_over_cpu_expansions": (out["config"]["astar"]["expansions_per_s"] / (last["astar_expansions"] / last["seconds"])
+                                            if last["astar_expansions"] > 0 else None),
             }
         else:
             out["cpu_baseline"] = {"value": None, "unit": "agent-steps/s", "cores": 1, "kind": "port",
