@@ -10,7 +10,7 @@ CMD="bench.py --warmup 0 --steps 6 --no-cpu-baseline --no-secondary"
 P1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 P2="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT"
 cd /tmp && export TMPDIR=/tmp
-for mode in plain quad; do
+for mode in ${MODES:-plain quad}; do
   if [ $mode = quad ]; then export TS_QUAD=1; else unset TS_QUAD; fi
   rm -rf /tmp/sq_${mode}_1 /tmp/sq_${mode}_2
   rocprofv3 --pmc $P1 -d /tmp/sq_${mode}_1 -o pmc -- python3 $R/$CMD > $OUT/r3_sq_${mode}_bench1.json 2> $OUT/r3_sq_${mode}_1.err

@@ -1163,18 +1163,34 @@ __device__ __attribute__((noinline)) int replan_turn(const Dev& d, const TsParam
   int i;
   if (j >= n3 + n2 + n1 + n0) {
     if (q.fb_waves == 0) return 0;
-    // this launch's own lists are done: take a ticket for the hand-back list and wait for its entry - or for the
-    // quads to finish without ever writing it
+    // this launch's own lists are done: serve the hand-back list.  An entry is only ever claimed once it has been produced
+    // (claimed <= produced at all times), so whatever is left when this wave gives up is a suffix the host can queue again.
+    // Giving up: all quad waves have counted themselves out, or nothing has moved for about three seconds (the two kernels
+    // were not run side by side - a profiler or debugger serialising launches; k_replan_quad is then yet to run).
     if (threadIdx.x == 0) {
-      const int t = atomicAdd(&d.cnt->quad_n[2], 1);
       int job = -1;
-      while (t < q.fb_cap) {
-        job = __hip_atomic_load(&q.fb_list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (job >= 0) break;
-        if (__hip_atomic_load(&d.cnt->quad_n[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= q.fb_waves) {
-          job = __hip_atomic_load(&q.fb_list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (published before the count)
-          break;
+      long long t_last = wall_clock64();
+      int seen = -1;
+      for (;;) {
+        const int produced = __hip_atomic_load(&d.cnt->quad_n[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        int claimed = __hip_atomic_load(&d.cnt->quad_n[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (claimed < produced) {
+          if (__hip_atomic_compare_exchange_strong(&d.cnt->quad_n[2], &claimed, claimed + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            // (the producer stores the entry right after counting it: a running wave, a few hundred cycles at most)
+            do job = __hip_atomic_load(&q.fb_list[claimed], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); while (job < 0);
+            break;
+          }
+          continue;
         }
+        const int done = __hip_atomic_load(&d.cnt->quad_n[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (done >= q.fb_waves) {
+          if (__hip_atomic_load(&d.cnt->quad_n[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == produced) break;   // nothing more can come
+          continue;
+        }
+        const int mark = produced + done + __hip_atomic_load(&d.cnt->quad_n[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long now = wall_clock64();
+        if (mark != seen) { seen = mark; t_last = now; }
+        else if (now - t_last > 300000000ll) break;          // 3 s of the 100 MHz clock
         __builtin_amdgcn_s_sleep(64);
       }
       g_job = job;

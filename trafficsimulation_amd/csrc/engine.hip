@@ -155,17 +155,19 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     if (getenv("TS_DEBUG_REPLAN"))
       fprintf(stderr, "[replan] tick %lld: %d entries to the quads (%d waves of %d), %d to k_replan (%d waves); handed over %d, pool-full %d, %.2f ms\n",
               (long long)e->C.step_count, nq, qgrid, e->qslots.n_slots / 16, nw, wgrid, fb, retry, now_ms() - tl);
-    if (qn[2] < fb) return fail(e, TS_E_DEVICE, "hand-back entries of the quad searcher were left unserved (internal error)");
-    // what found the path pool full is queued again below
+    // what k_replan did not get to serve of the hand-backs (it only gives up on them when the two kernels were not run side
+    // by side) and what found the path pool full is queued again below
+    const int served = std::min(qn[2], fb), left = fb - served;
     if (retry > 0) {
       d.pool_cap_words = e->pool_cap;
       rc = pool_make_room(e, (size_t)retry * 1024 + (1u << 20));
       if (rc) return rc;
-      HIPOK(hipMemcpyAsync(e->replan_list[0], e->replan_list[4], (size_t)retry * 4, hipMemcpyDeviceToDevice, st));
     }
+    if (left > 0) HIPOK(hipMemcpyAsync(e->replan_list[0], e->replan_list[5] + served, (size_t)left * 4, hipMemcpyDeviceToDevice, st));
+    if (retry > 0) HIPOK(hipMemcpyAsync(e->replan_list[0] + left, e->replan_list[4], (size_t)retry * 4, hipMemcpyDeviceToDevice, st));
     const int keep_owned = e->hint[8 + 6];
     for (int q = 0; q < 8; q++) e->hint[8 + q] = 0;
-    e->hint[8] = retry; e->hint[8 + 6] = keep_owned;
+    e->hint[8] = left + retry; e->hint[8 + 6] = keep_owned;
     HIPOK(hipMemcpyAsync(d.cnt->replan_n, e->hint + 8, sizeof(int) * 8, hipMemcpyHostToDevice, st));
   }
   while (replan_pending(e->hint + 8) > 0) {
