@@ -93,6 +93,7 @@ struct QState {
   int soft;
   int n_exp, n_relax;
   unsigned long long xpre;  // heap entry hs - 1 when it lies beyond LDS (requested at the end of the previous turn)
+  int why;                  // why the search was abandoned (1 window / g, 2 heap, 3 expansion budget, 4 path buffer): ts_debug statistics
 #ifdef TS_QUAD_PROF
   long long pf[8], pt;
 #endif
@@ -128,9 +129,18 @@ __device__ __forceinline__ uint32_t q_aix(const QConst& K, int x, int y) {
 // are touched in blocks of their own, which only run for quads whose heap has outgrown LDS.
 __device__ __forceinline__ u64 q_lget(const QConst& K, int k) { return q_lds[K.lbase + k]; }
 __device__ __forceinline__ void q_lput(const QConst& K, int k, u64 v) { q_lds[K.lbase + k] = v; }
+// A load from the HBM spill in one of the turn's rare side paths, waited for on the spot and kept out of the compiler's
+// bookkeeping of outstanding memory operations: a load it can see behind a branch costs an unconditional
+// `s_waitcnt vmcnt(0)` where the branch rejoins - for every quad of the wave, on every turn, and with the turn's stores
+// (table records, heap entries) in flight that is a wait of microseconds.
+__device__ __forceinline__ u64 q_gload_now(const TS_GLOBAL u64* p) {
+  u64 v;
+  asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
 __device__ __forceinline__ u64 q_hget(const QConst& K, int k) {
   u64 v;
-  if (k < QL) v = q_lds[K.lbase + k]; else v = K.gq[k - QL];
+  if (k < QL) v = q_lds[K.lbase + k]; else v = q_gload_now(K.gq + (k - QL));
   return v;
 }
 __device__ __forceinline__ void q_hput(const QConst& K, int k, u64 v) {
@@ -138,38 +148,67 @@ __device__ __forceinline__ void q_hput(const QConst& K, int k, u64 v) {
 }
 
 // Two levels of heap_sift_down (astar_numba.py:67-85) below the hole at slot p: lanes 0 / 1 of the quad fetch the hole's
-// children (2 / 3 mirror them), the four lanes its four grandchildren; every lane decides with its sibling's key (one DPP
-// swap) whether its entry would move up if its parent were the hole - smallest of (x, left, right), ties to x, then to
-// the left - and one OR over the quad tells every lane the path.  Returns true when x has found its place (p).
+// children (2 / 3 mirror them), the four lanes its four grandchildren (quad_sift2_load); every lane decides with its
+// sibling's key (one DPP swap) whether its entry would move up if its parent were the hole - smallest of (x, left, right),
+// ties to x, then to the left - and one OR over the quad tells every lane the path (quad_sift2_apply).  apply returns
+// true when x has found its place (p).  `wr0` / `wr1`: the slots it wrote (-1: none), for whoever holds copies of them.
+struct QPair { u64 ce, ge; bool cv, gv; };
 template <bool DEEP>
-__device__ __forceinline__ bool quad_sift2(const QConst& K, int& p, int size, int xf) {
+__device__ __forceinline__ QPair quad_sift2_load(const QConst& K, int p, int size) {
   const int j = K.j, side = j & 1;
   const int c = 2 * p + 1 + side, gc = 4 * p + 3 + j;
-  const bool cv = c < size, gv = gc < size;
-  u64 ce = 0, ge = 0;
-  if (cv) ce = DEEP ? q_hget(K, c) : q_lget(K, c);
-  if (gv) ge = DEEP ? q_hget(K, gc) : q_lget(K, gc);
-  const int cf = cv ? hq_f(ce) : 0x7FFFFFFF, gf = gv ? hq_f(ge) : 0x7FFFFFFF;
+  QPair r;
+  r.cv = c < size; r.gv = gc < size;
+  r.ce = 0; r.ge = 0;
+  if (r.cv) r.ce = DEEP ? q_hget(K, c) : q_lget(K, c);
+  if (r.gv) r.ge = DEEP ? q_hget(K, gc) : q_lget(K, gc);
+  return r;
+}
+// The same fetch with nothing conditional about it: an LDS read and an HBM load per entry, both always issued (clamped to
+// a valid address when the slot lies on the other side or does not exist), the right one picked afterwards.  A load the
+// compiler can count is a load it can wait for precisely: behind a branch it would make every later wait for an older
+// load (the expansion's map entries and table records) a wait for all of them.
+struct QBoth { u64 cl, cg, gl, gg; int c, gc; bool cv, gv; };
+__device__ __forceinline__ QBoth quad_sift2_load_both(const QConst& K, int p, int size) {
+  const int j = K.j, side = j & 1;
+  QBoth r;
+  r.c = 2 * p + 1 + side; r.gc = 4 * p + 3 + j;
+  r.cv = r.c < size; r.gv = r.gc < size;
+  r.cl = q_lget(K, min(r.c, QL - 1)); r.gl = q_lget(K, min(r.gc, QL - 1));
+  r.cg = K.gq[max(min(r.c, QL + Q_SPILL - 1) - QL, 0)]; r.gg = K.gq[max(min(r.gc, QL + Q_SPILL - 1) - QL, 0)];
+  return r;
+}
+template <bool DEEP>
+__device__ __forceinline__ bool quad_sift2_apply(const QConst& K, int& p, int xf, const QPair& r, int& wr0, int& wr1) {
+  const int j = K.j, side = j & 1;
+  const int cf = r.cv ? hq_f(r.ce) : 0x7FFFFFFF, gf = r.gv ? hq_f(r.ge) : 0x7FFFFFFF;
   const int csf = qperm<QP_SWAP1>(cf), gsf = qperm<QP_SWAP1>(gf);
   const unsigned adj = (unsigned)(side ^ 1);
   const bool cw = (unsigned)cf < min((unsigned)xf, (unsigned)csf + adj);
   const bool gw = (unsigned)gf < min((unsigned)xf, (unsigned)gsf + adj);
   const int bits = quad_or((cw ? (1 << j) : 0) | (gw ? (16 << j) : 0));
   const int w1 = bits & 3;
+  wr0 = -1; wr1 = -1;
   if (w1 == 0) return true;
   const int sdn = w1 >> 1;                              // the hole moves to the left (0) / right (1) child
-  if (cw & (j < 2)) { if (DEEP) q_hput(K, p, ce); else q_lput(K, p, ce); }
+  if (cw & (j < 2)) { if (DEEP) q_hput(K, p, r.ce); else q_lput(K, p, r.ce); }
+  wr0 = p;
   const int pc = 2 * p + 1 + sdn;
   const int w2 = (bits >> (4 + 2 * sdn)) & 3;
   if (w2 == 0) { p = pc; return true; }
   const int t = 2 * sdn + (w2 >> 1);                    // ... and on to grandchild t
-  if (j == t) { if (DEEP) q_hput(K, pc, ge); else q_lput(K, pc, ge); }
+  if (j == t) { if (DEEP) q_hput(K, pc, r.ge); else q_lput(K, pc, r.ge); }
+  wr1 = pc;
   p = 4 * p + 3 + t;
   return false;
 }
 
 // One turn of astar_core's main loop (astar_numba.py:136-237) for every quad whose search is on.  Returns the quad's
 // new state: QS_SEARCH, QS_FOUND (the goal was popped), QS_EMPTY (heap empty: `return []`) or QS_ABANDON.
+// Order of the turn (what the reference does one after the other is only reordered where the results cannot tell):
+//   pop -> the expansion's loads leave (map entries, table records; the parents of the next two heap slots when they lie
+//   beyond LDS) -> sift-down through the levels in LDS -> the loads of its first two levels beyond LDS leave -> the popped
+//   cell's neighbours are evaluated (registers only) while those travel -> the sift-down finishes -> table records, pushes.
 __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
   if (s.hs <= 0) return QS_EMPTY;
   const int j = K.j;
@@ -205,68 +244,107 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
   const uint32_t t_l = K.tab[t_ix];
   const uint32_t am_c = *(const TS_GLOBAL uint32_t*)((const TS_GLOBAL char*)K.amap + (uint32_t)(a_ixc << 3));
   const uint32_t t_c = K.tab[t_ixc];
+  // the pushes of this turn go to slots last_i, last_i + 1, ...: lane j will want ancestor 1 + j of each.  Of those only
+  // the parent generation can lie beyond LDS (slots below 4 QL): lanes 0 request the parents of the first two slots now
+  // (pa0 / pa1: those parent slots, -1 = not held; every lane knows them, lane 0 holds the entries)
+  int pa0 = last_i > 2 * QL ? (last_i - 1) >> 1 : -1, pa1 = last_i + 1 > 2 * QL ? last_i >> 1 : -1;
+  // (both loads always leave - of the spill's first entry when there is nothing to fetch: see quad_sift2_load_both)
+  const u64 pv0 = K.gq[max(pa0 - QL, 0)], pv1 = K.gq[max(pa1 - QL, 0)];
   QP(0);
+  int p = 0;
+  bool sinking = false;
+  u64 x = 0;
+  int xf = 0;
   if (last_i > 0) {
     s.dir0 = xd;
     const u64 xl = q_lget(K, min(last_i, QL - 1));
-    const u64 x = last_i < QL ? xl : s.xpre;
-    const int xf = hq_f(x);
-    int p = 0;
+    x = last_i < QL ? xl : s.xpre;
+    xf = hq_f(x);
     bool done = false;
+    int w0, w1;
     // (a step reads slots up to 4 p + 6: LDS-only code while those that exist all lie below QL)
-    while (!done && (last_i <= QL || 4 * p + 6 < QL)) done = quad_sift2<false>(K, p, last_i, xf);
-    QP(1);
-    if (!done) {
-      do done = quad_sift2<true>(K, p, last_i, xf); while (!done);
+    while (!done && (last_i <= QL || 4 * p + 6 < QL)) {
+      const QPair r = quad_sift2_load<false>(K, p, last_i);
+      done = quad_sift2_apply<false>(K, p, xf, r, w0, w1);
+    }
+    sinking = !done;
+  }
+  const QBoth db = quad_sift2_load_both(K, sinking ? p : 0, sinking ? last_i : 0);     // (on their way while the neighbours are evaluated)
+  QP(1);
+  // ---- lane j evaluates neighbour j (171-225) in half units, exactly as astar_loop<HALF> does: registers only
+  const bool is_goal = cxy == s.goal_xy;                        // (151: before the staleness test)
+  const int g = f_top - (abs(cx - s.gx) + abs(cy - s.gy));
+  const int dist_c = ((t_c ^ s.stamp) >> Q_STAMP_SHIFT) == 0u ? (int)(t_c & Q_DIST_MASK) : A_INF;
+  const bool stale = g > dist_c;                                // (165)
+  const uint32_t a_l = (uint32_t)am_l;
+  const bool node_l = (uint32_t)(am_l >> 32) != 0xFFFFFFFFu;
+  const int dist_l = ((t_l ^ s.stamp) >> Q_STAMP_SHIFT) == 0u ? (int)(t_l & Q_DIST_MASK) : A_INF;
+  const bool n_occ = ((a_l >> 8) & 1u) != 0u, n_stop = ((a_l >> 9) & 1u) != 0u, n_road = ((a_l >> 4) & 1u) != 0u;
+  const uint32_t rt = (a_l >> 6) & 3u;
+  const bool flow = ((am_c >> j) & 1u) != 0u;
+  const bool turn = K.turn_on & (prev_dir != -1) & (j != prev_dir);
+  int n2 = 2 * (g + 1);
+  n2 += turn ? K.turn2 : 0;
+  n2 += n_occ ? (int)(a_l >> AMAP_PEN_SHIFT) : 0;
+  n2 += n_stop ? K.stop2 : 0;
+  const int rtp = rt == 1u ? K.rt2_1 : rt == 2u ? K.rt2_2 : rt == 3u ? K.rt2_3 : 0;
+  n2 += (K.rt_on & n_road) ? rtp : 0;
+  const bool ok = !is_goal & !stale & inb & node_l & flow & ((s.soft != 0) | !(n_occ | n_stop)) & (n2 < 2 * dist_l);
+  const int ngi = n2 >> 1;
+  // what this searcher cannot carry: a g beyond the record's 22 bits, a cell the table window would alias
+  bool bad = ok & (ngi > (int)Q_DIST_MASK);
+  if (K.chk_x) bad |= ok & (abs(nx - s.sx) >= K.half_w);
+  if (K.chk_y) bad |= ok & (abs(ny - s.sy) >= K.half_h);
+  int relax = quad_or((ok ? (1 << j) : 0) | (bad ? 16 : 0));
+  const int nf_l = ngi + abs(nx - s.gx) + abs(ny - s.gy);
+  const int nxy_l = (int)((uint32_t)nx | ((uint32_t)ny << 16));
+  QP(3);
+  // ---- the sift-down finishes beyond LDS.  (Every path takes delivery of the two entries here, before the turn's stores
+  // leave: a load still pending on some path would be waited for behind them - stores included - where its register is
+  // next written.)
+  asm volatile("" : : "v"(relax), "v"(nf_l), "v"(nxy_l), "v"(ngi));   // (the evaluation first ...)
+  asm volatile("" : : "v"(db.cg), "v"(db.gg), "v"(pv0), "v"(pv1));
+  QPair dp;
+  dp.cv = db.cv; dp.gv = db.gv;
+  dp.ce = db.c < QL ? db.cl : db.cg;
+  dp.ge = db.gc < QL ? db.gl : db.gg;
+  if (last_i > 0) {
+    if (sinking) {
+      bool done;
+      int w0, w1;
+      done = quad_sift2_apply<true>(K, p, xf, dp, w0, w1);
+      if ((w0 >= 0) & ((w0 == pa0) | (w0 == pa1))) { if (w0 == pa0) pa0 = -1; if (w0 == pa1) pa1 = -1; }
+      if ((w1 >= 0) & ((w1 == pa0) | (w1 == pa1))) { if (w1 == pa0) pa0 = -1; if (w1 == pa1) pa1 = -1; }
+      while (!done) {
+        const QPair r = quad_sift2_load<true>(K, p, last_i);
+        done = quad_sift2_apply<true>(K, p, xf, r, w0, w1);
+        if ((w0 >= 0) & ((w0 == pa0) | (w0 == pa1))) { if (w0 == pa0) pa0 = -1; if (w0 == pa1) pa1 = -1; }
+        if ((w1 >= 0) & ((w1 == pa0) | (w1 == pa1))) { if (w1 == pa0) pa0 = -1; if (w1 == pa1) pa1 = -1; }
+      }
     }
     if (j == 0) q_hput(K, p, x);
+    if (p == pa0) pa0 = -1;
+    if (p == pa1) pa1 = -1;
   }
   wave_mem_sync();
   QP(2);
   int st = QS_SEARCH;
   do {
-    if (cxy == s.goal_xy) { st = QS_FOUND; break; }   // (151: before the staleness test)
-    const int g = f_top - (abs(cx - s.gx) + abs(cy - s.gy));
-    {
-      const int dist_c = ((t_c ^ s.stamp) >> Q_STAMP_SHIFT) == 0u ? (int)(t_c & Q_DIST_MASK) : A_INF;
-      if (g > dist_c) break;      // (165)
-    }
+    if (is_goal) { st = QS_FOUND; break; }
+    if (stale) break;
     s.n_exp++;
-    if (s.n_exp > Q_MAX_EXP) { st = QS_ABANDON; break; }   // a long search: k_replan's single search is the faster one
-    QP(3);
-    // ---- lane j evaluates neighbour j (171-225) in half units, exactly as astar_loop<HALF> does
-    const uint32_t a_l = (uint32_t)am_l;
-    const bool node_l = (uint32_t)(am_l >> 32) != 0xFFFFFFFFu;
-    const int dist_l = ((t_l ^ s.stamp) >> Q_STAMP_SHIFT) == 0u ? (int)(t_l & Q_DIST_MASK) : A_INF;
-    const bool n_occ = ((a_l >> 8) & 1u) != 0u, n_stop = ((a_l >> 9) & 1u) != 0u, n_road = ((a_l >> 4) & 1u) != 0u;
-    const uint32_t rt = (a_l >> 6) & 3u;
-    const bool flow = ((am_c >> j) & 1u) != 0u;
-    const bool turn = K.turn_on & (prev_dir != -1) & (j != prev_dir);
-    int n2 = 2 * (g + 1);
-    n2 += turn ? K.turn2 : 0;
-    n2 += n_occ ? (int)(a_l >> AMAP_PEN_SHIFT) : 0;
-    n2 += n_stop ? K.stop2 : 0;
-    const int rtp = rt == 1u ? K.rt2_1 : rt == 2u ? K.rt2_2 : rt == 3u ? K.rt2_3 : 0;
-    n2 += (K.rt_on & n_road) ? rtp : 0;
-    const bool ok = inb & node_l & flow & ((s.soft != 0) | !(n_occ | n_stop)) & (n2 < 2 * dist_l);
-    const int ngi = n2 >> 1;
-    // what this searcher cannot carry: a g beyond the record's 22 bits, a cell the table window would alias
-    bool bad = ok & (ngi > (int)Q_DIST_MASK);
-    if (K.chk_x) bad |= ok & (abs(nx - s.sx) >= K.half_w);
-    if (K.chk_y) bad |= ok & (abs(ny - s.sy) >= K.half_h);
-    int relax = quad_or((ok ? (1 << j) : 0) | (bad ? 16 : 0));
-    if (relax & 16) { st = QS_ABANDON; break; }
+    if (s.n_exp > Q_MAX_EXP) { st = QS_ABANDON; s.why = 3; break; }   // a long search: k_replan's single search is the faster one
+    if (relax & 16) { st = QS_ABANDON; s.why = 1; break; }
     if (relax == 0) break;
     const int n_new = __builtin_popcount((unsigned)relax);
-    if (s.hs + n_new > QL + Q_SPILL) { st = QS_ABANDON; break; }
+    if (s.hs + n_new > QL + Q_SPILL) { st = QS_ABANDON; s.why = 2; break; }
     s.n_relax += n_new;
     if (ok) K.tab[t_ix] = (uint32_t)ngi | ((uint32_t)j << Q_DIR_SHIFT) | s.stamp;   // dist / came_from (226-227)
-    const int nf_l = ngi + abs(nx - s.gx) + abs(ny - s.gy);
-    const int nxy_l = (int)((uint32_t)nx | ((uint32_t)ny << 16));
     const int nf0 = qperm<QP_B0>(nf_l), nf1 = qperm<QP_B1>(nf_l), nf2 = qperm<QP_B2>(nf_l), nf3 = qperm<QP_B3>(nf_l);
     const int nc0 = qperm<QP_B0>(nxy_l), nc1 = qperm<QP_B1>(nxy_l), nc2 = qperm<QP_B2>(nxy_l), nc3 = qperm<QP_B3>(nxy_l);
     QP(4);
     // ---- heap pushes in the reference's order N, E, S, W (229-237)
+    int npush = 0;
     while (relax) {
       const int dd = __builtin_ctz((unsigned)relax);
       relax &= relax - 1;
@@ -279,32 +357,42 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
         s.dwin = (s.dwin & ~(3ull << sh)) | ((u64)(unsigned)dd << sh);
       }
       // heap_sift_up (52-65): the four lanes fetch four ancestors of slot i at a time; ancestor k = ((i + 1) >> k) - 1.
-      // (only the parent generation of a slot beyond 2 QL can lie beyond LDS: ancestors 5 and up are below QL for every
-      // heap the spill can hold)
+      // (only the parent generation of a slot beyond 2 QL can lie beyond LDS - ancestors 2 and up are below QL for every
+      // slot below 4 QL + 3, beyond that they are fetched like any slot; the parent of the first two pushes of a turn was
+      // requested at the pop, unless something has written to it since)
       const int depth = 31 - __builtin_clz((unsigned)(i + 1));
+      const int pa = npush == 0 ? pa0 : npush == 1 ? pa1 : -1;
+      const u64 pv = npush == 0 ? pv0 : pv1;
       int rise = 0;
       for (int base = 0; base < depth; base += 4) {
         const int k = base + 1 + j;
         const bool has = k <= depth;
         const int a = (int)(((unsigned)(i + 1) >> (k & 31)) - 1u);
         u64 anc = 0;
-        if (base == 0 && i > 2 * QL) { if (has) anc = q_hget(K, a); }
+        if (base == 0 && i > 2 * QL) {
+          if (has) { if (a == pa) anc = pv; else anc = q_hget(K, a); }
+        }
         else if (has) anc = q_lget(K, a);
         const bool up = has & (nf < hq_f(anc));
         const int um = quad_or(up ? (1 << j) : 0);
         const int cnt = __builtin_ctz(~(unsigned)um);      // the entry passes a PREFIX of its ancestors (heap order)
-        if (up) q_hput(K, (int)(((unsigned)(i + 1) >> ((k - 1) & 31)) - 1u), anc);   // ancestor k moves to where k - 1 was
+        const int dst = (int)(((unsigned)(i + 1) >> ((k - 1) & 31)) - 1u);
+        if (up) q_hput(K, dst, anc);                       // ancestor k moves to where k - 1 was
         rise += cnt;
         if (cnt < 4) break;
       }
-      if (j == 0) q_hput(K, (int)(((unsigned)(i + 1) >> (rise & 31)) - 1u), hq_pack(nf, nxy));
+      const int fin = (int)(((unsigned)(i + 1) >> (rise & 31)) - 1u);
+      if (j == 0) q_hput(K, fin, hq_pack(nf, nxy));
+      // (the copy of the next push's parent is stale once this push has risen past it: the only slot of pa1's level it writes)
+      if (rise >= 1 && pa1 == ((i - 1) >> 1)) pa1 = -1;
       s.hs = i + 1;
+      npush++;
       wave_mem_sync();
     }
   } while (0);
   QP(5);
   // the entry the next pop moves to the root, if it lies beyond LDS: on its way while this turn ends and the next begins
-  if (st == QS_SEARCH && s.hs - 1 >= QL) s.xpre = K.gq[s.hs - 1 - QL];
+  s.xpre = K.gq[max(s.hs - 1 - QL, 0)];
   QP(6);
   return st;
 }
@@ -345,7 +433,7 @@ __device__ __attribute__((noinline)) int quad_policy(const Dev& d, const TsParam
       atomicAdd((unsigned long long*)&d.cnt->astar_relax, (unsigned long long)S.relaxations);
       if (q.owned_list) q.owned_list[atomicAdd(&d.cnt->replan_n[6], 1)] = i;
     } else if (r == DV_POOL_FULL) q.retry_list[atomicAdd(&d.cnt->replan_n[4], 1)] = i;
-    else __hip_atomic_store(&q.fallback_list[atomicAdd(&d.cnt->quad_n[0], 1)], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // DV_BAIL, DV_OVERFLOW: k_replan takes the vehicle
+    else { atomicAdd(&d.cnt->dbg[r == DV_BAIL ? 5 : 6], 1); __hip_atomic_store(&q.fallback_list[atomicAdd(&d.cnt->quad_n[0], 1)], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // DV_BAIL, DV_OVERFLOW: k_replan takes the vehicle
   }
   return r;
 }
@@ -379,7 +467,7 @@ __global__ void __launch_bounds__(64) k_replan_quad(Dev d, TsParams P, QSlots qs
   K.rt2_3 = (int)((double)P.road_type_penalty_r3 * 2.0);
   uint32_t epoch = qs.slot_epoch[slot];
   QState s;
-  s.hs = 0; s.dir0 = -1; s.wb = 0; s.dwin = 0; s.xpre = 0; s.gx = s.gy = s.sx = s.sy = 0; s.goal_xy = 0; s.stamp = 0; s.soft = 0; s.n_exp = 0; s.n_relax = 0;
+  s.hs = 0; s.dir0 = -1; s.wb = 0; s.dwin = 0; s.xpre = 0; s.why = 0; s.gx = s.gy = s.sx = s.sy = 0; s.goal_xy = 0; s.stamp = 0; s.soft = 0; s.n_exp = 0; s.n_relax = 0;
   QReq req;
   req.start = req.goal = req.soft = req.cap = 0; req.out = nullptr;
   int st = QS_NEEDJOB, job = -1, n_done = 0;
@@ -416,7 +504,7 @@ __global__ void __launch_bounds__(64) k_replan_quad(Dev d, TsParams P, QSlots qs
             }
           wave_mem_sync();
         }
-        if (len < 0) st = QS_ABANDON;
+        if (len < 0) { st = QS_ABANDON; s.why = 4; }
         else {
           int32_t* lg = qs.log + (size_t)slot * (3 * QLOG) + 3 * n_done;
           lg[0] = len; lg[1] = s.n_exp; lg[2] = s.n_relax;
@@ -425,6 +513,7 @@ __global__ void __launch_bounds__(64) k_replan_quad(Dev d, TsParams P, QSlots qs
         }
       }
       if (st == QS_ABANDON) {
+        if (one) atomicAdd(&d.cnt->dbg[s.why & 7], 1);
         if (one) __hip_atomic_store(&fallback_list[atomicAdd(&d.cnt->quad_n[0], 1)], job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         st = QS_NEEDJOB;
       }

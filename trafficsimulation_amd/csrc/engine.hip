@@ -152,6 +152,11 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
       HIPOK(hipMemset(d.cnt->qprof, 0, sizeof(qp)));
     }
 #endif
+    if (getenv("TS_DEBUG_REPLAN")) {
+      int dbg[8];
+      HIPOK(hipMemcpy(dbg, d.cnt->dbg, sizeof(dbg), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[replan] hand-backs so far by reason: window / g %d, heap %d, expansion budget %d, path buffer %d, policy (step-limited / contraflow search) %d, other %d\n", dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
+    }
     if (getenv("TS_DEBUG_REPLAN"))
       fprintf(stderr, "[replan] tick %lld: %d entries to the quads (%d waves of %d), %d to k_replan (%d waves); handed over %d, pool-full %d, %.2f ms\n",
               (long long)e->C.step_count, nq, qgrid, e->qslots.n_slots / 16, nw, wgrid, fb, retry, now_ms() - tl);
