@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N>1: nccl = RCCL over xGMI (one GPU per rank); gloo = host collectives, for "
                          "rehearsing the N>1 path with several ranks on one GPU (local rank r uses device r %% visible devices)")
+    ap.add_argument("--exchange", choices=["device", "host"], default="device",
+                    help="sharded mode: records exchanged between device buffers (default) or staged through host memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the reduced-policy legs of the N=1 line")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
@@ -220,6 +222,7 @@ def main():
 
     from trafficsimulation_amd._lib import new_engine
     from trafficsimulation_amd import dist as tdist
+    from trafficsimulation_amd import _capi as capi_mod
     seed = args.seed + (1000 * rank if (world > 1 and mode == "replicas") else 0)
     tables, routes, gen_t = make_workload(args.size, args.vehicles, seed, args.world)
     _rl = np.diff(np.asarray(routes[2], dtype=np.int64))      # cells per initial route (routes = starts, goals, offsets, directions)
@@ -237,7 +240,9 @@ def main():
     sharder = None
     setup(api, tables, routes, seed, policy=args.policy)
     if world > 1 and mode == "sharded":
-        sharder = tdist.ShardedReplans(device=coll_dev if args.backend == "nccl" else None).attach(api)
+        # (the records stay in device memory: one all_gather_into_tensor over RCCL; --exchange host = the host-staged form)
+        sharder = tdist.ShardedReplans(device=torch.device("cuda", local_rank) if (args.exchange == "device" or args.backend == "nccl") else None,
+                                       device_direct=args.exchange == "device").attach(api)
     v0 = api.num_vehicles()
     t_w = time.perf_counter()
     api.step(args.warmup)
@@ -268,6 +273,14 @@ def main():
             steps_done = int(ss.item())
     prof = api.profile()
     live_end = api.num_vehicles()
+    # sharded mode: every rank must hold the same world after the run (both RNG streams, the counters the searches feed)
+    same_state = None
+    if world > 1 and mode == "sharded":
+        mine = [list(api.rng_fingerprint(capi_mod.RNG_GLOBAL)), list(api.rng_fingerprint(capi_mod.RNG_SCHEDULER)), int(c1.agent_steps),
+                int(c1.astar_calls), int(c1.stuck), int(c1.count_completed_through), int(live_end)]
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        same_state = all(x == every[0] for x in every)
     api.close()
 
     out = None
@@ -344,6 +357,7 @@ def main():
                 "initial_route_cells": route_stats,
                 "grid": args.size, "vehicles": v0, "live_vehicles_end": live_end,
                 "light_groups": int(len(tables["g_light_off"]) - 1),
+                "ranks_hold_identical_state": same_state,
                 "multi_gpu_mode": ("single GPU" if world == 1 else
                                    "replicated state, sharded replans (one world on all ranks, bit-exact)" if mode == "sharded"
                                    else "replicas (independent worlds, bit-exact)"),

@@ -401,6 +401,12 @@ int ts_set_device(int32_t device);
  * is an all_gather on RCCL (backend "nccl") or gloo: trafficsimulation_amd/dist.py.  world == 1 switches it off. */
 typedef int (*ts_exchange_fn)(void* user, const void* send, int64_t send_bytes, void** recv, int64_t** sizes, int64_t* stride);
 int ts_set_replan_sharding(ts_handle h, int32_t rank, int32_t world, ts_exchange_fn exchange, void* user);
+/* The same with the buffers in DEVICE memory (the form for RCCL): `send` is a device pointer to this rank's packed records
+ * (valid until the call returns), `recv` must come back as a device pointer to world slots of `stride` bytes each, readable
+ * by the engine's stream when the call returns and owned by the callee until the next call; `sizes` stays a host array.
+ * The payload never visits the host: one all_gather_into_tensor between pre-sized device buffers
+ * (trafficsimulation_amd/dist.py: ShardedReplans(device_direct=True)). */
+int ts_set_replan_sharding_device(ts_handle h, int32_t rank, int32_t world, ts_exchange_fn exchange, void* user);
 
 /* Per-kernel timing with HIP events recorded on the engine's own stream (bench.py's roofline leg).
  * ts_profile_enable(h, 1) starts collecting; ts_profile_get returns, for kernel class `kernel_id`

@@ -1914,6 +1914,7 @@ int tso_astar(ts_handle e, int32_t sx, int32_t sy, int32_t gx, int32_t gy, int32
 int tso_set_device(int32_t) { return TS_OK; }
 // (the checker is a single sequential process: there is nothing to shard)
 int tso_set_replan_sharding(ts_handle, int32_t, int32_t world, ts_exchange_fn, void*) { return world == 1 ? TS_OK : TS_E_UNSUPPORTED; }
+int tso_set_replan_sharding_device(ts_handle, int32_t, int32_t world, ts_exchange_fn, void*) { return world == 1 ? TS_OK : TS_E_UNSUPPORTED; }
 int tso_profile_enable(ts_handle, int32_t) { return TS_OK; }
 int tso_profile_count(void) { return 0; }
 const char* tso_profile_name(int32_t) { return ""; }

@@ -32,7 +32,11 @@ for name in %(traces)r:
     api = new_engine()
     setup_from_trace(api, tr, explicit_paths=False)
     check_initial(api, tr)
-    sr = tdist.ShardedReplans().attach(api)
+    if %(device_direct)r:
+        import torch
+        sr = tdist.ShardedReplans(device=torch.device("cuda", 0), device_direct=True).attach(api)
+    else:
+        sr = tdist.ShardedReplans().attach(api)
     n = replay_and_compare(api, tr)          # raises on the first tick that differs from the reference
     c = api.counters()
     res[name] = dict(ticks=n, astar_calls=int(c.astar_calls), want_calls=int(tr["astar_calls_spawn"]) + int(tr["astar_per_tick"].sum()),
@@ -43,30 +47,42 @@ d.destroy_process_group()
 '''
 
 
-def test_two_ranks_sharded_replans_match_the_reference():
+@pytest.mark.parametrize("world,device_direct", [(2, False), (2, True), (4, True), (5, True)])
+def test_ranks_sharded_replans_match_the_reference(world, device_direct):
+    """2, 4 and 5 ranks (with the test runner itself that is the six processes this box lets share its GPU), with the records exchanged between device buffers
+    (ts_set_replan_sharding_device; the collective itself is gloo here) and once with the host-staged form."""
     # closed populations, then the agents that step on the host inside the shuffled order (traffic generator spawning and
     # planning mid-tick, service vehicles with their arrival records, rain): every rank runs those redundantly
     traces = ["full_64_s1", "full_96_s8", "faults_64_s9", "carve_96_s10", "dta_64_s12", "rain_96_s14", "config1_64_s11", "despawn_96_s25", "startgoal_96_s27"]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world > 2:
+        traces = ["full_96_s8", "faults_64_s9", "dta_64_s12", "config1_64_s11", "startgoal_96_s27"]
+    port = str(29541 + world + (10 if device_direct else 0))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
-        f.write(WORKER % dict(root=ROOT, traces=traces))
+        f.write(WORKER % dict(root=ROOT, traces=traces, device_direct=device_direct))
         path = f.name
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29541", path]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", port, path]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     os.unlink(path)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     rows = [json.loads(line) for line in out.stdout.splitlines() if line.startswith('{"rank"')]
-    assert sorted(r["rank"] for r in rows) == [0, 1]
-    r0, r1 = sorted(rows, key=lambda r: r["rank"])
+    assert sorted(r["rank"] for r in rows) == list(range(world))
+    rows = sorted(rows, key=lambda r: r["rank"])
+    r0 = rows[0]
     for name in traces:
-        a, b = r0["res"][name], r1["res"][name]
-        assert a["ticks"] == b["ticks"] > 0
-        if name != "config1_64_s11":     # (service vehicles plan inside the generator's step too: not in the fixture's per-tick count)
-            assert a["astar_calls"] == b["astar_calls"] == a["want_calls"]     # the searches of both ranks add up to the reference's
-        assert a["astar_calls"] == b["astar_calls"]
-        assert a["fp"] == b["fp"]
-        assert a["exchanges"] == b["exchanges"] > 0 and a["bytes"] > 0 and b["bytes"] > 0   # both ranks planned something
+        a = r0["res"][name]
+        for rb in rows[1:]:
+            b = rb["res"][name]
+            assert a["ticks"] == b["ticks"] > 0
+            if name != "config1_64_s11":     # (service vehicles plan inside the generator's step too: not in the fixture's per-tick count)
+                assert a["astar_calls"] == b["astar_calls"] == a["want_calls"]     # the searches of all ranks add up to the reference's
+            assert a["astar_calls"] == b["astar_calls"]
+            assert a["fp"] == b["fp"]
+            assert a["exchanges"] == b["exchanges"] > 0
+        assert sum(rb["res"][name]["bytes"] for rb in rows) > 0
+        if world == 2:
+            assert all(rb["res"][name]["bytes"] > 0 for rb in rows)       # both ranks planned something
 
 
 NCCL_WORKER = r'''
@@ -109,3 +125,18 @@ def test_exchange_collective_over_rccl():
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     row = json.loads([line for line in out.stdout.splitlines() if line.startswith("{")][-1])
     assert row["ok"] and row["backend"] == "nccl" and row["calls"] == 5
+
+
+
+def test_bench_two_ranks_over_gloo_smoke():
+    """`python bench.py --gpus 2` end to end on this box's one GPU (gloo, sharded replans, device-direct exchange): the line
+    reports the process group's size and that both ranks ended in the same state."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "512", "--vehicles", "12000",
+           "--steps", "4", "--warmup", "4", "--no-cpu-baseline", "--no-secondary"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    row = json.loads([line for line in out.stdout.splitlines() if line.startswith("{")][-1])
+    assert row["n_gpus"] == 2 and row["scaling"] == "strong"
+    assert row["config"]["ranks_hold_identical_state"] is True
+    assert row["config"]["exchange"]["calls"] > 0 and row["config"]["astar"]["calls"] > 1000

@@ -245,6 +245,8 @@ class CApi:
         f("debug_set_occupancy").argtypes = [C.c_void_p, C.c_void_p]
         f("set_device").argtypes = [C.c_int32]
         f("set_replan_sharding").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        if True:
+            f("set_replan_sharding_device").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         f("profile_enable").argtypes = [C.c_void_p, C.c_int32]
         f("profile_name").restype = C.c_char_p
         f("profile_name").argtypes = [C.c_int32]
@@ -446,11 +448,13 @@ class CApi:
             out[self._f("profile_name")(k).decode()] = (ms.value, n.value, it.value)
         return out
 
-    def set_replan_sharding(self, rank: int, world: int, callback):
-        """ts_set_replan_sharding: `callback` is an EXCHANGE_FN instance (kept alive here) or None for world == 1."""
+    def set_replan_sharding(self, rank: int, world: int, callback, device_buffers: bool = False):
+        """ts_set_replan_sharding (host buffers) / ts_set_replan_sharding_device (device buffers): `callback` is an
+        EXCHANGE_FN instance (kept alive here) or None for world == 1."""
         self._exchange_cb = callback
         ptr = C.cast(callback, C.c_void_p) if callback is not None else None
-        self._chk(self._f("set_replan_sharding")(self.h, int(rank), int(world), ptr, None))
+        name = "set_replan_sharding_device" if device_buffers else "set_replan_sharding"
+        self._chk(self._f(name)(self.h, int(rank), int(world), ptr, None))
 
     def debug_set_occupancy(self, arr):
         """Test hook: overwrite occupancy_map without placing vehicles (A*/density KATs)."""

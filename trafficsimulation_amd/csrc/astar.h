@@ -1131,6 +1131,25 @@ __global__ void k_decide_main(Dev d, TsParams P, int lo, int n_active, RLists li
 // sort key of a replanning entry (run_replans): expected cost, largest first (bit length of the expansions, see cost_bits),
 // then the Morton index of the 32 x 32-cell block its vehicle stands in
 constexpr int REPLAN_KEY_BITS = 21;
+// The same with the entry itself (its decide-order index) below the key: a total order, the same on every rank of a sharded
+// run whatever order k_decide_main's atomics left the list in, so that ranks can split the queue by POSITION (entry j of
+// the sorted queue belongs to rank j % world: every rank gets every world-th search of every cost class and every
+// neighbourhood - the longest searches are dealt out one by one instead of falling where index % world puts them).
+__global__ void k_replan_keys64(Dev d, const int32_t* list, int n, unsigned long long* keys) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int i = list[j];
+  const int vid = d.active[i];
+  int x = 0, y = 0, bits = 0;
+  if (vid >= 0) { cell_xy(d, d.pos[vid], x, y); bits = min(replan_cost_bits(d, vid), 31); }
+  uint32_t bx = (uint32_t)x >> 5, by = (uint32_t)y >> 5, k = 0;
+  for (int b = 0; b < 8; b++) k |= ((bx >> b) & 1u) << (2 * b) | ((by >> b) & 1u) << (2 * b + 1);
+  keys[j] = ((unsigned long long)(((uint32_t)(31 - max(bits, 16)) << 16) | k) << 32) | (unsigned long long)(uint32_t)i;
+}
+__global__ void k_replan_unkey64(const unsigned long long* keys, int n, int32_t* list) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) list[j] = (int32_t)(uint32_t)keys[j];
+}
 __global__ void k_replan_keys(Dev d, const int32_t* list, int n, uint32_t* keys) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -1205,7 +1224,9 @@ __device__ __attribute__((noinline)) int replan_turn(const Dev& d, const TsParam
   else if (j < n3 + n2 + n1) i = q.l[1][j - n3 - n2];
   else i = q.l[0][j - n3 - n2 - n1];
   i = uni(i);
-  if (q.world > 1 && (i % q.world) != q.rank) return 1;
+  // (sharded mode: the queue is in the same total order on every rank - run_replans sorts it by (key, index) - and entry j
+  // of it is rank j % world's; hand-backs of this rank's own quads are this rank's)
+  if (q.world > 1 && j < n3 + n2 + n1 + n0 && (j % q.world) != q.rank) return 1;
   const long long c0 = S->calls, e0 = S->expansions, r0 = S->relaxations;
   const int r = uni(decide_vehicle<DM_WAVE>(d, P, i, S));
   if (threadIdx.x == 0) {
@@ -1298,7 +1319,7 @@ __global__ void k_replan_export(Dev d, const int32_t* owned, int n, ReplanRec* r
   recs[t] = r;
 }
 // the same in the other direction: records of vehicles another rank planned (pool capacity ensured by the host)
-__global__ void k_replan_import(Dev d, const ReplanRec* recs, int n, const uint32_t* words) {
+__global__ void k_replan_import(Dev d, const ReplanRec* __restrict__ recs, int n, const uint32_t* __restrict__ words) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const ReplanRec r = recs[t];

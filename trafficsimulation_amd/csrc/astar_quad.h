@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(64) k_replan_quad(Dev d, TsParams P, QSlots qs
         else if (t < n3 + n2) i = q.l[2][t - n3];
         else if (t < n3 + n2 + n1) i = q.l[1][t - n3 - n2];
         else i = q.l[0][t - n3 - n2 - n1];
-        if (world > 1 && (i % world) != rank) continue;
+        if (world > 1 && (t % world) != rank) continue;      // (position in the totally ordered queue, as in replan_turn)
         job = i; n_done = 0;
         st = QS_POLICY;
       }

@@ -76,15 +76,30 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   // read the same few megabytes of the map snapshot, which stay in the XCDs' L2s instead of competing with thousands of
   // private tables for the MALL.  The order of the queue does not touch any result.
   static const bool spatial = !getenv("TS_NO_SPATIAL_QUEUE");
-  for (int h = 0; h < 4 && spatial; h++) {
+  const bool sharded = e->dist_world > 1;      // (then the order must be total and the same on every rank: 64-bit keys, every list)
+  for (int h = 0; h < 4 && (spatial || sharded); h++) {
     const int n = e->hint[8 + h];
-    if (n < 256) continue;
+    if (n < (sharded ? 2 : 256)) continue;
     if ((size_t)n > e->cap_sortbuf) {
       const size_t nc = (size_t)n * 2;
-      rc = regrow(e, &e->sort_keys, 0, nc); if (rc) return rc;
-      rc = regrow(e, &e->sort_keys_alt, 0, nc); if (rc) return rc;
+      rc = regrow(e, &e->sort_keys, 0, nc * 2); if (rc) return rc;          // (room for 64-bit keys)
+      rc = regrow(e, &e->sort_keys_alt, 0, nc * 2); if (rc) return rc;
       rc = regrow(e, &e->sort_vals_alt, 0, nc); if (rc) return rc;
       e->cap_sortbuf = nc;
+    }
+    if (sharded) {
+      unsigned long long* k0 = (unsigned long long*)e->sort_keys;
+      unsigned long long* k1 = (unsigned long long*)e->sort_keys_alt;
+      hipLaunchKernelGGL(k_replan_keys64, dim3(nblk(n)), dim3(BLK), 0, st, d, e->replan_list[h], n, k0);
+      size_t tmp_bytes = 0;
+      HIPOK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, k0, k1, n, 0, 32 + REPLAN_KEY_BITS, st));
+      if (tmp_bytes > e->cap_sorttmp) {
+        rc = regrow(e, &e->sort_tmp, 0, tmp_bytes * 2); if (rc) return rc;
+        e->cap_sorttmp = tmp_bytes * 2;
+      }
+      HIPOK(hipcub::DeviceRadixSort::SortKeys(e->sort_tmp, tmp_bytes, k0, k1, n, 0, 32 + REPLAN_KEY_BITS, st));
+      hipLaunchKernelGGL(k_replan_unkey64, dim3(nblk(n)), dim3(BLK), 0, st, k1, n, e->replan_list[h]);
+      continue;
     }
     hipLaunchKernelGGL(k_replan_keys, dim3(nblk(n)), dim3(BLK), 0, st, d, e->replan_list[h], n, e->sort_keys);
     size_t tmp_bytes = 0;
@@ -102,11 +117,13 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   // the quads hand back as they work (searches that outgrow their window, heap or expansion budget, step-limited ones).
   // Smaller queues are bounded by their longest search, and that one is faster alone on a wave.
   const int quad_min = getenv("TS_QUAD_MIN") ? atoi(getenv("TS_QUAD_MIN")) : 65536;
+  bool split_done = false;      // (the queue is split between the ranks once; what is queued again - pool-full entries, hand-backs - is this rank's own)
   if (e->quad_on && replan_pending(e->hint + 8) >= std::max(quad_min, 1)) {
     const int quad_mask = getenv("TS_QUAD_CLASSES") ? atoi(getenv("TS_QUAD_CLASSES")) & 15 : 7;
     int nq = 0, nw = 0;
     for (int c = 0; c < 4; c++) { if ((quad_mask >> c) & 1) nq += e->hint[8 + c]; else nw += e->hint[8 + c]; }
     const double tl = now_ms();
+    split_done = true;
     HIPOK(hipMemsetAsync(d.cnt->quad_n, 0, sizeof(int) * 4, st));
     int tok = prof_begin(e, PK_REPLAN, nq + nw);
     int qgrid = 0;
@@ -178,7 +195,9 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   while (replan_pending(e->hint + 8) > 0) {
     const int n = replan_pending(e->hint + 8);
     const int grid = std::min(n, e->slots.n_slots);
-    LAUNCH(e, PK_REPLAN, n, k_replan, dim3(grid), dim3(64), d, P, e->slots, rl, e->replan_list[4], e->dist_rank, e->dist_world,
+    const int w_rank = split_done ? 0 : e->dist_rank, w_world = split_done ? 1 : e->dist_world;
+    split_done = true;
+    LAUNCH(e, PK_REPLAN, n, k_replan, dim3(grid), dim3(64), d, P, e->slots, rl, e->replan_list[4], w_rank, w_world,
            e->dist_world > 1 ? e->owned_list : nullptr, 15, (int32_t*)nullptr, 0, 0);
     const double tl = now_ms();
     HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
@@ -229,7 +248,13 @@ int exchange_replans(E* e, const DevCnt& before, int local_rc) {
     void* recv = nullptr;
     int64_t* sizes = nullptr;
     int64_t stride = 0;
-    (void)e->dist_fn(e->dist_user, e->send_buf.data(), (int64_t)sizeof(hd), &recv, &sizes, &stride);
+    const void* sendp = e->send_buf.data();
+    if (e->dist_dev) {
+      if (e->cap_send < sizeof(hd) && regrow(e, &e->d_send, 0, (size_t)4096) == TS_OK) e->cap_send = 4096;
+      if (e->cap_send >= sizeof(hd) && hipMemcpy(e->d_send, &hd, sizeof(hd), hipMemcpyHostToDevice) == hipSuccess) sendp = e->d_send;
+      else return local_rc;     // (no device memory left even for a header: the other ranks run into their collective's time-out)
+    }
+    (void)e->dist_fn(e->dist_user, sendp, (int64_t)sizeof(hd), &recv, &sizes, &stride);
     return local_rc;
   }
   const int n_owned = e->hint[8 + 6];
@@ -274,6 +299,77 @@ int exchange_replans(E* e, const DevCnt& before, int local_rc) {
   hd.delta[13] = after.dec_arrived;
   hd.ddelta[0] = after.dur_internal - before.dur_internal; hd.ddelta[1] = after.dur_through - before.dur_through;
   const size_t bytes = sizeof(XHeader) + (size_t)n_owned * sizeof(ReplanRec) + (size_t)n_words * 4 + (size_t)std::max(n_arr, 0) * 12;
+  if (e->dist_dev) {
+    // ---- device-direct exchange: header | records | words | service records packed in device memory, gathered by the
+    // callback between device buffers, imported straight out of the gathered slots
+    if (bytes > e->cap_send) {
+      const size_t nc = bytes * 2 + 4096;
+      int rc = regrow(e, &e->d_send, 0, nc); if (rc) return rc;
+      e->cap_send = nc;
+    }
+    uint8_t* p = e->d_send;
+    HIPOK(hipMemcpyAsync(p, &hd, sizeof(hd), hipMemcpyHostToDevice, st)); p += sizeof(hd);
+    if (n_owned > 0) HIPOK(hipMemcpyAsync(p, e->d_recs, (size_t)n_owned * sizeof(ReplanRec), hipMemcpyDeviceToDevice, st));
+    p += (size_t)n_owned * sizeof(ReplanRec);
+    if (n_words > 0) HIPOK(hipMemcpyAsync(p, e->d_xwords, (size_t)n_words * 4, hipMemcpyDeviceToDevice, st));
+    p += (size_t)n_words * 4;
+    if (n_arr > 0) HIPOK(hipMemcpyAsync(p, d.arr + 3 * (size_t)before.arr_n, (size_t)n_arr * 12, hipMemcpyDeviceToDevice, st));
+    HIPOK(hipStreamSynchronize(st));
+    void* recv = nullptr;
+    int64_t* sizes = nullptr;
+    int64_t stride = 0;
+    const int xrc = e->dist_fn(e->dist_user, e->d_send, (int64_t)bytes, &recv, &sizes, &stride);
+    if (xrc != 0 || !recv || !sizes) return fail(e, TS_E_DEVICE, "the replan exchange callback failed");
+    std::vector<XHeader> hs((size_t)e->dist_world);
+    for (int r = 0; r < e->dist_world; r++) {
+      if (r == e->dist_rank) continue;
+      if ((size_t)sizes[r] < sizeof(XHeader)) return fail(e, TS_E_DEVICE, "short replan exchange buffer");
+      HIPOK(hipMemcpyAsync(&hs[r], (const uint8_t*)recv + (size_t)r * (size_t)stride, sizeof(XHeader), hipMemcpyDeviceToHost, st));
+    }
+    HIPOK(hipStreamSynchronize(st));
+    DevCnt merged = after;
+    long long in_words = 0, in_arr = 0;
+    for (int r = 0; r < e->dist_world; r++) {
+      if (r == e->dist_rank) continue;
+      const XHeader& h2 = hs[r];
+      if (h2.delta[14]) return fail(e, (int)h2.delta[14], "rank " + std::to_string(r) + " failed in its share of the replans (error " + std::to_string((long long)h2.delta[14]) + ")");
+      in_words += h2.n_words; in_arr += h2.n_arr;
+      if ((size_t)sizes[r] != sizeof(XHeader) + (size_t)h2.n_recs * sizeof(ReplanRec) + (size_t)h2.n_words * 4 + (size_t)h2.n_arr * 12)
+        return fail(e, TS_E_DEVICE, "replan exchange buffer size mismatch");
+    }
+    if (in_words > 0) { int rc = pool_make_room(e, (size_t)in_words + 64); if (rc) return rc; }
+    if (in_arr > 0 && (long long)after.arr_n + in_arr > d.arr_cap) return fail(e, TS_E_CAPACITY, "more service records in one tick than the record buffer holds");
+    e->exchange_bytes += (long long)bytes;
+    int arr_at = after.arr_n;
+    for (int r = 0; r < e->dist_world; r++) {
+      if (r == e->dist_rank) continue;
+      const XHeader& h2 = hs[r];
+      const uint8_t* q = (const uint8_t*)recv + (size_t)r * (size_t)stride + sizeof(XHeader);
+      merged.stuck += h2.delta[0]; merged.collisions += h2.delta[1]; merged.malfunctions += h2.delta[2]; merged.overtaking += h2.delta[3];
+      merged.in_stuck_detour += h2.delta[4]; merged.parked += h2.delta[5]; merged.completed_internal += h2.delta[6];
+      merged.completed_through += h2.delta[7]; merged.dist_internal += h2.delta[8]; merged.dist_through += h2.delta[9];
+      merged.astar_calls += h2.delta[10]; merged.astar_exp += h2.delta[11]; merged.astar_relax += h2.delta[12];
+      merged.dur_internal += h2.ddelta[0]; merged.dur_through += h2.ddelta[1];
+      if (h2.error && !merged.error) merged.error = (int)h2.error;
+      if ((int)h2.delta[13] > merged.dec_arrived) merged.dec_arrived = (int)h2.delta[13];
+      if (h2.n_recs > 0)
+        hipLaunchKernelGGL(k_replan_import, dim3(nblk((long long)h2.n_recs)), dim3(BLK), 0, st, d, (const ReplanRec*)q, (int)h2.n_recs,
+                           (const uint32_t*)(q + (size_t)h2.n_recs * sizeof(ReplanRec)));
+      if (h2.n_arr > 0) {
+        HIPOK(hipMemcpyAsync(d.arr + 3 * (size_t)arr_at, q + (size_t)h2.n_recs * sizeof(ReplanRec) + (size_t)h2.n_words * 4, (size_t)h2.n_arr * 12, hipMemcpyDeviceToDevice, st));
+        arr_at += (int)h2.n_arr;
+      }
+    }
+    unsigned long long pool_now = 0;
+    HIPOK(hipMemcpyAsync(&pool_now, &d.cnt->pool_used, sizeof(pool_now), hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));     // (the gathered slots are the callee's again after this tick's imports)
+    merged.pool_used = pool_now; merged.arr_n = arr_at;
+    *e->hcnt = merged;
+    HIPOK(hipMemcpyAsync(d.cnt, e->hcnt, sizeof(DevCnt), hipMemcpyHostToDevice, st));
+    HIPOK(hipStreamSynchronize(st));
+    e->exchange_ms += now_ms() - t0;
+    return TS_OK;
+  }
   e->send_buf.resize(bytes);
   uint8_t* p = e->send_buf.data();
   memcpy(p, &hd, sizeof(hd)); p += sizeof(hd);
@@ -1796,8 +1892,13 @@ int ts_counters(ts_handle e, TsCounters* out) {
 int ts_set_replan_sharding(ts_handle e, int32_t rank, int32_t world, ts_exchange_fn fn, void* user) {
   if (!e || world < 1 || rank < 0 || rank >= world) return TS_E_INVALID;
   if (world > 1 && !fn) return fail(e, TS_E_INVALID, "sharded replans need an exchange callback");
-  e->dist_rank = rank; e->dist_world = world; e->dist_fn = world > 1 ? fn : nullptr; e->dist_user = user;
+  e->dist_rank = rank; e->dist_world = world; e->dist_fn = world > 1 ? fn : nullptr; e->dist_user = user; e->dist_dev = false;
   return TS_OK;
+}
+int ts_set_replan_sharding_device(ts_handle e, int32_t rank, int32_t world, ts_exchange_fn fn, void* user) {
+  int rc = ts_set_replan_sharding(e, rank, world, fn, user);
+  if (rc == TS_OK) e->dist_dev = world > 1;
+  return rc;
 }
 
 // profiling hook (not part of include/trafficsim.h): the eight debug words the last replanning / search kernel left

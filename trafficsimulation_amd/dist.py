@@ -57,9 +57,15 @@ class ShardedReplans:
         api.step(n)                              # every rank the same calls
     """
 
-    def __init__(self, group=None, device=None, all_gather=None, rank=None, world=None):
+    def __init__(self, group=None, device=None, all_gather=None, rank=None, world=None, device_direct=False):
         self.group = group
         self.device = device
+        # device_direct: the engine hands over and takes back DEVICE pointers (ts_set_replan_sharding_device): the records
+        # stay in HBM, one all_gather_into_tensor between pre-sized device buffers moves them (RCCL over xGMI with backend
+        # "nccl"; with "gloo" the collective itself is staged through the host, the engine's side is the same)
+        self.device_direct = bool(device_direct)
+        self._send_t = None
+        self._recv_t = None
         self.bytes_sent = 0
         self.calls = 0
         self._keep = None
@@ -111,12 +117,76 @@ class ShardedReplans:
             print(f"[ShardedReplans] exchange failed on rank {self.rank}: {ex!r}", file=sys.stderr, flush=True)
             return -1
 
+    # ---- device-direct form ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _wrap_device(ptr, nbytes, device):
+        """A uint8 torch tensor over `nbytes` of device memory at `ptr` (no copy; the engine owns the memory)."""
+        import torch
+
+        class _Raw:
+            __cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(_Raw(), device=device)
+
+    def gather_device(self, send_ptr, nbytes):
+        """all-gather of this rank's `nbytes` at device pointer `send_ptr`: -> (device tensor of world * stride bytes, sizes, stride)."""
+        import torch
+        import torch.distributed as dist
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        nccl = self._backend() == "nccl"
+        cdev = dev if nccl else "cpu"
+        n = torch.tensor([int(nbytes)], dtype=torch.int64, device=cdev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(self.world)]
+        self._all_gather(sizes, n)
+        sizes = [int(x.item()) for x in sizes]
+        stride = (max(max(sizes), 1) + 255) // 256 * 256
+        if self._send_t is None or self._send_t.numel() < stride:      # pre-sized, grown geometrically, reused every tick
+            cap = max(stride * 2, 1 << 16)
+            self._send_t = torch.empty(cap, dtype=torch.uint8, device=dev)
+            self._recv_t = torch.empty(cap * self.world, dtype=torch.uint8, device=dev)
+        send_t = self._send_t[:stride]
+        if nbytes > 0:
+            send_t[:nbytes].copy_(self._wrap_device(send_ptr, nbytes, dev))
+        recv_t = self._recv_t[:stride * self.world]
+        if nccl:
+            dist.all_gather_into_tensor(recv_t, send_t, group=self.group)
+        else:      # gloo: the collective on host copies, the result back in device memory
+            host = send_t.cpu()
+            outs = [torch.empty(stride, dtype=torch.uint8) for _ in range(self.world)]
+            self._all_gather(outs, host)
+            recv_t.copy_(torch.cat(outs))
+        torch.cuda.synchronize(dev)          # the engine's stream reads the slots next
+        self.bytes_sent += int(nbytes)
+        self.calls += 1
+        return recv_t, sizes, stride
+
+    def _backend(self):
+        try:
+            import torch.distributed as dist
+            return dist.get_backend(self.group)
+        except Exception:
+            return "injected"
+
+    def _callback_dev(self, user, send, nbytes, recv_pp, sizes_pp, stride_p):
+        import ctypes as C
+        try:
+            recv_t, sizes, stride = self.gather_device(send, nbytes)
+            self._keep = recv_t                                  # owned by us until the next call
+            self._sizes = (C.c_int64 * self.world)(*sizes)
+            recv_pp[0] = recv_t.data_ptr()
+            sizes_pp[0] = C.cast(self._sizes, C.c_void_p).value
+            stride_p[0] = stride
+            return 0
+        except Exception as ex:      # never let an exception cross the C boundary
+            import sys
+            print(f"[ShardedReplans] device exchange failed on rank {self.rank}: {ex!r}", file=sys.stderr, flush=True)
+            return -1
+
     def attach(self, api):
         """Switch `api`'s engine to sharded replans over this group (world 1 = plain single-GPU stepping)."""
         from . import _capi as capi
         if self.world == 1:
             api.set_replan_sharding(0, 1, None)
             return self
-        self._cb = capi.EXCHANGE_FN(self._callback)
-        api.set_replan_sharding(self.rank, self.world, self._cb)
+        self._cb = capi.EXCHANGE_FN(self._callback_dev if self.device_direct else self._callback)
+        api.set_replan_sharding(self.rank, self.world, self._cb, device_buffers=self.device_direct)
         return self
