@@ -415,3 +415,15 @@ def test_hip_quad_searcher_vs_oracle_512_through_a_replanning_wave(monkeypatch):
     h, c = _pair_full(512, 12_000, 7)
     ch = _compare_full(h, c, 9)
     assert ch.astar_calls > 5_000 and ch.astar_expansions > 1_000_000
+
+
+def test_hip_quad_and_wave_searchers_share_the_table_arena(monkeypatch):
+    """TS_QUAD=1 as it runs by default thresholds, scaled down: the replanning wave of a 768 x 768 world goes to the quads
+    (TS_QUAD_MIN=5000), the ticks before and after it to k_replan on all its slots - and the quads' tables alias k_replan's
+    (1024 quad slots fit behind the side waves' slots here), so the arena is cleared and changes hands twice inside the run."""
+    monkeypatch.setenv("TS_QUAD", "1")
+    monkeypatch.setenv("TS_QUAD_MIN", "5000")
+    monkeypatch.setenv("TS_QUAD_SLOTS", "1024")
+    h, c = _pair_full(768, 30_000, 3)
+    ch = _compare_full(h, c, 9, every=1)
+    assert ch.astar_calls > 20_000

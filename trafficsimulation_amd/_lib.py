@@ -8,7 +8,8 @@ import os
 from ._capi import CApi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libtrafficsim_hip.so")
+# (TS_HIP_LIB: another build of the same engine - the test build with the small LDS heap, an experiment - in place of the default)
+LIB_PATH = os.environ.get("TS_HIP_LIB") or os.path.join(HERE, "csrc", "libtrafficsim_hip.so")
 _lib = None
 
 

@@ -15,10 +15,10 @@
 //     last slot and written at the slots behind it - a stack.  Two bits per slot, the 32 slots around the heap's end in
 //     a register pair, the rest in HBM; slot 0 in a register of its own;
 //   * dist / came_from: one 4-byte record per CELL (dist 22 bits | direction 2 | epoch stamp 8) in a table that is a
-//     1024 x 1024-cell window addressed by the cell's coordinates modulo the window (8 x 8-tiled): the record's address
+//     1152 x 1152-cell window centred on the search's start (8 x 8-tiled, addressed by the cell's offset in it): the record's address
 //     does not depend on the map entry, so both loads of an expansion leave together (k_replan's node-numbered table costs
-//     a dependent second round trip), and a searcher costs 4 MB instead of 8 bytes per road cell of the whole map.  A
-//     search that relaxes a cell 512 or more columns / rows away from its start, whose g reaches 2^22, whose heap outgrows
+//     a dependent second round trip), and a searcher costs 5.3 MB instead of 8 bytes per road cell of the whole map.  A
+//     search that reaches a cell 576 or more columns / rows away from its start, whose g reaches 2^22, whose heap outgrows
 //     the spill or whose path outgrows the buffers is abandoned, and its vehicle goes to k_replan's queue (nothing of it
 //     has been committed: step_decide is a pure function of the tick-start state until its last lines);
 //   * half-unit integer costs only (astar_half_units: the reference's defaults), no step limit, no contraflow, no
@@ -44,7 +44,11 @@ constexpr int QL = TS_QUAD_LCAP;            // heap slots per search in LDS (and
 // (bank spread: the 8-byte slots of the eight quads of a half-wave at the same heap index must fall into different banks)
 static_assert(QL % 8 == 4, "TS_QUAD_LCAP must be 4 mod 8 (LDS bank spread between the quads of a wave)");
 static_assert((size_t)16 * QL * 8 * TS_QUAD_WAVES_PER_CU <= 160 * 1024 - 512, "the LDS heaps of TS_QUAD_WAVES_PER_CU waves must fit a CU");
-constexpr int QT_LOG_MAX = 10;              // table window: at most 1024 x 1024 cells
+#ifndef TS_QUAD_WINDOW
+#define TS_QUAD_WINDOW 1152
+#endif
+constexpr int QT_MAX = TS_QUAD_WINDOW;       // table window: at most 1152 x 1152 cells around the search's start (a multiple of 8)
+static_assert(QT_MAX % 8 == 0, "the table window is 8 x 8-tiled");
 constexpr int Q_CELLS = 4096;               // path buffer capacity per search (cells)
 constexpr int Q_SPILL = 7936;               // heap slots per search beyond LDS (HBM)
 #ifndef TS_QUAD_MAX_EXP
@@ -56,8 +60,8 @@ enum { QS_NEEDJOB = 0, QS_POLICY = 1, QS_SEARCH = 2, QS_FOUND = 3, QS_EMPTY = 4,
 
 struct QSlots {
   int n_slots;            // searches = quads: sixteen per wave
-  int tw_log, th_log;     // table window: 2^tw_log x 2^th_log cells (the whole map when it is smaller)
-  int chk_x, chk_y;       // the map is wider / taller than the window: relaxations are bounded to the window around the start
+  int tw, th;             // table window in cells, multiples of 8 (the whole map when it is smaller)
+  int chk_x, chk_y;       // the map is wider / taller than the window: it is centred on the search's start and relaxations are bounded to it
   size_t tab_entries;     // per slot
   uint32_t* tab;
   unsigned long long* gq; // per slot Q_SPILL entries
@@ -88,6 +92,7 @@ struct QState {
   int wb;                   // first slot of the direction window (a multiple of 16)
   unsigned long long dwin;  // dir_arr[wb .. wb + 32), two bits per slot
   int gx, gy, sx, sy;
+  int ox, oy;               // origin of the table window
   uint32_t goal_xy;         // x | y << 16
   uint32_t stamp;           // epoch << 24
   int soft;
@@ -112,14 +117,16 @@ struct QConst {   // per quad, fixed for the kernel's lifetime
   int dx, dy;
   // wave-uniform
   const TS_GLOBAL u64* amap;
-  int W, H, W8, twm, thm, tw8_log, chk_x, chk_y, half_w, half_h;
+  int W, H, W8, tw, th, tw8, chk_x, chk_y;
   int turn2, stop2, rt2_1, rt2_2, rt2_3;
   bool turn_on, rt_on;
 };
 
-__device__ __forceinline__ uint32_t q_tix(const QConst& K, int x, int y) {
-  const uint32_t xm = (uint32_t)x & (uint32_t)K.twm, ym = (uint32_t)y & (uint32_t)K.thm;
-  return ((((ym >> 3) << K.tw8_log) + (xm >> 3)) << 6) | ((ym & 7u) << 3) | (xm & 7u);
+// the table record of cell (x, y): the window's origin (ox, oy) is the search's start minus half a window when the map is
+// larger than the window, (0, 0) otherwise
+__device__ __forceinline__ uint32_t q_tix(const QConst& K, int ox, int oy, int x, int y) {
+  const uint32_t xm = (uint32_t)(x - ox), ym = (uint32_t)(y - oy);
+  return ((__umul24(ym >> 3, (uint32_t)K.tw8) + (xm >> 3)) << 6) | ((ym & 7u) << 3) | (xm & 7u);
 }
 __device__ __forceinline__ uint32_t q_aix(const QConst& K, int x, int y) {
   return (((__umul24((uint32_t)(y >> 3), (uint32_t)K.W8) + (uint32_t)(x >> 3)) << 6) | (uint32_t)((y & 7) << 3) | (uint32_t)(x & 7));
@@ -237,9 +244,10 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
   // the table record of neighbour j, every lane (one request) the popped cell's own
   const int nx = cx + K.dx, ny = cy + K.dy;
   const bool inb = (unsigned)nx < (unsigned)K.W && (unsigned)ny < (unsigned)K.H;
-  const uint32_t a_ixc = q_aix(K, cx, cy), t_ixc = q_tix(K, cx, cy);
+  const uint32_t a_ixc = q_aix(K, cx, cy), t_ixc = q_tix(K, s.ox, s.oy, cx, cy);
   const uint32_t a_ix = inb ? q_aix(K, nx, ny) : a_ixc;
-  const uint32_t t_ix = inb ? q_tix(K, nx, ny) : t_ixc;
+  const bool inw = inb & ((unsigned)(nx - s.ox) < (unsigned)K.tw) & ((unsigned)(ny - s.oy) < (unsigned)K.th);
+  const uint32_t t_ix = inw ? q_tix(K, s.ox, s.oy, nx, ny) : t_ixc;
   const u64 am_l = ld8(K.amap, a_ix);
   const uint32_t t_l = K.tab[t_ix];
   const uint32_t am_c = *(const TS_GLOBAL uint32_t*)((const TS_GLOBAL char*)K.amap + (uint32_t)(a_ixc << 3));
@@ -289,12 +297,12 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
   n2 += n_stop ? K.stop2 : 0;
   const int rtp = rt == 1u ? K.rt2_1 : rt == 2u ? K.rt2_2 : rt == 3u ? K.rt2_3 : 0;
   n2 += (K.rt_on & n_road) ? rtp : 0;
-  const bool ok = !is_goal & !stale & inb & node_l & flow & ((s.soft != 0) | !(n_occ | n_stop)) & (n2 < 2 * dist_l);
+  const bool cand = !is_goal & !stale & inb & node_l & flow & ((s.soft != 0) | !(n_occ | n_stop));
+  const bool ok = cand & inw & (n2 < 2 * dist_l);
   const int ngi = n2 >> 1;
-  // what this searcher cannot carry: a g beyond the record's 22 bits, a cell the table window would alias
-  bool bad = ok & (ngi > (int)Q_DIST_MASK);
-  if (K.chk_x) bad |= ok & (abs(nx - s.sx) >= K.half_w);
-  if (K.chk_y) bad |= ok & (abs(ny - s.sy) >= K.half_h);
+  // what this searcher cannot carry: a g beyond the record's 22 bits, a neighbour outside the table window (its record
+  // cannot be consulted: whether it would be relaxed is unknowable here)
+  const bool bad = (ok & (ngi > (int)Q_DIST_MASK)) | (cand & !inw);
   int relax = quad_or((ok ? (1 << j) : 0) | (bad ? 16 : 0));
   const int nf_l = ngi + abs(nx - s.gx) + abs(ny - s.gy);
   const int nxy_l = (int)((uint32_t)nx | ((uint32_t)ny << 16));
@@ -459,15 +467,15 @@ __global__ void __launch_bounds__(64) k_replan_quad(Dev d, TsParams P, QSlots qs
   K.dx = (j == 1) - (j == 3); K.dy = (j == 0) - (j == 2);
   K.amap = (const TS_GLOBAL u64*)(uintptr_t)uni64((u64)(uintptr_t)d.amap);
   K.W = uni(d.W); K.H = uni(d.H); K.W8 = uni(d.W8);
-  K.twm = (1 << qs.tw_log) - 1; K.thm = (1 << qs.th_log) - 1; K.tw8_log = qs.tw_log - 3;
-  K.chk_x = qs.chk_x; K.chk_y = qs.chk_y; K.half_w = 1 << (qs.tw_log - 1); K.half_h = 1 << (qs.th_log - 1);
+  K.tw = qs.tw; K.th = qs.th; K.tw8 = qs.tw >> 3;
+  K.chk_x = qs.chk_x; K.chk_y = qs.chk_y;
   K.turn_on = P.turn_penalty_enabled != 0; K.rt_on = P.road_type_penalties_enabled != 0;
   K.turn2 = (int)((double)P.turn_penalty * 2.0); K.stop2 = (int)((double)P.obstacle_penalty_stop * 2.0);
   K.rt2_1 = (int)((double)P.road_type_penalty_r1 * 2.0); K.rt2_2 = (int)((double)P.road_type_penalty_r2 * 2.0);
   K.rt2_3 = (int)((double)P.road_type_penalty_r3 * 2.0);
   uint32_t epoch = qs.slot_epoch[slot];
   QState s;
-  s.hs = 0; s.dir0 = -1; s.wb = 0; s.dwin = 0; s.xpre = 0; s.why = 0; s.gx = s.gy = s.sx = s.sy = 0; s.goal_xy = 0; s.stamp = 0; s.soft = 0; s.n_exp = 0; s.n_relax = 0;
+  s.hs = 0; s.dir0 = -1; s.wb = 0; s.dwin = 0; s.xpre = 0; s.why = 0; s.gx = s.gy = s.sx = s.sy = 0; s.ox = s.oy = 0; s.goal_xy = 0; s.stamp = 0; s.soft = 0; s.n_exp = 0; s.n_relax = 0;
   QReq req;
   req.start = req.goal = req.soft = req.cap = 0; req.out = nullptr;
   int st = QS_NEEDJOB, job = -1, n_done = 0;
@@ -491,7 +499,7 @@ __global__ void __launch_bounds__(64) k_replan_quad(Dev d, TsParams P, QSlots qs
             if (len >= req.cap) { len = -1; break; }
             outg[req.cap - 1 - len] = py * K.W + px;
             len++;
-            const int dd = (int)((tab[q_tix(K, px, py)] >> Q_DIR_SHIFT) & 3u);
+            const int dd = (int)((tab[q_tix(K, s.ox, s.oy, px, py)] >> Q_DIR_SHIFT) & 3u);
             px -= (dd == 1) - (dd == 3); py -= (dd == 0) - (dd == 2);
           }
           wave_mem_sync();
@@ -545,13 +553,14 @@ __global__ void __launch_bounds__(64) k_replan_quad(Dev d, TsParams P, QSlots qs
         int gxx, gyy, sxx, syy;
         cell_xy(d, req.goal, gxx, gyy); cell_xy(d, req.start, sxx, syy);
         s.gx = gxx; s.gy = gyy; s.sx = sxx; s.sy = syy;
+        s.ox = K.chk_x ? sxx - (K.tw >> 1) : 0; s.oy = K.chk_y ? syy - (K.th >> 1) : 0;
         s.goal_xy = (uint32_t)gxx | ((uint32_t)gyy << 16);
         s.stamp = epoch << Q_STAMP_SHIFT;
         s.soft = req.soft;
         s.n_exp = 0; s.n_relax = 0;
         s.dir0 = -1; s.wb = 0; s.dwin = 0;
         if (one) {
-          K.tab[q_tix(K, sxx, syy)] = s.stamp;    // dist 0
+          K.tab[q_tix(K, s.ox, s.oy, sxx, syy)] = s.stamp;    // dist 0
           q_lds[K.lbase] = hq_pack(abs(sxx - gxx) + abs(syy - gyy), (int)((uint32_t)sxx | ((uint32_t)syy << 16)));
         }
         s.hs = 1;

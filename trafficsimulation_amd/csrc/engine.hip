@@ -111,19 +111,23 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     HIPOK(hipcub::DeviceRadixSort::SortPairs(e->sort_tmp, tmp_bytes, e->sort_keys, e->sort_keys_alt, e->replan_list[h], e->sort_vals_alt, n, 0, REPLAN_KEY_BITS, st));
     HIPOK(hipMemcpyAsync(e->replan_list[h], e->sort_vals_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
   }
-  // The quad searcher (astar_quad.h; opt-in with TS_QUAD=1, see DESIGN.md section 4c for why it is not the default): a big
+  // The quad searcher (astar_quad.h; TS_QUAD=0 switches it off): a big
   // queue (a replanning wave of TS_QUAD_MIN entries or more) sends the classes in TS_QUAD_CLASSES to k_replan_quad (sixteen
   // searches per wave, on its own stream) while k_replan runs beside it on the most expensive class and on every vehicle
   // the quads hand back as they work (searches that outgrow their window, heap or expansion budget, step-limited ones).
   // Smaller queues are bounded by their longest search, and that one is faster alone on a wave.
   const int quad_min = getenv("TS_QUAD_MIN") ? atoi(getenv("TS_QUAD_MIN")) : 65536;
   bool split_done = false;      // (the queue is split between the ranks once; what is queued again - pool-full entries, hand-backs - is this rank's own)
-  if (e->quad_on && replan_pending(e->hint + 8) >= std::max(quad_min, 1)) {
+  // (not in the sharded multi-GPU mode: its ranks split one queue between k_replan launches)
+  if (e->quad_on && e->dist_world == 1 && replan_pending(e->hint + 8) >= std::max(quad_min, 1)) { rc = ensure_qslots(e); if (rc) return rc; }
+  if (e->quad_on && e->qslots_ready && e->dist_world == 1 && replan_pending(e->hint + 8) >= std::max(quad_min, 1)) {
     const int quad_mask = getenv("TS_QUAD_CLASSES") ? atoi(getenv("TS_QUAD_CLASSES")) & 15 : 7;
     int nq = 0, nw = 0;
     for (int c = 0; c < 4; c++) { if ((quad_mask >> c) & 1) nq += e->hint[8 + c]; else nw += e->hint[8 + c]; }
     const double tl = now_ms();
     split_done = true;
+    rc = arena_to_quads(e);
+    if (rc) return rc;
     HIPOK(hipMemsetAsync(d.cnt->quad_n, 0, sizeof(int) * 4, st));
     int tok = prof_begin(e, PK_REPLAN, nq + nw);
     int qgrid = 0;
@@ -140,7 +144,7 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     // (k_replan never holds anything the quads wait for: were the two launches ever serialised, it would simply find the
     // hand-back list complete)
     const int side_waves = getenv("TS_QUAD_SIDE_WAVES") ? atoi(getenv("TS_QUAD_SIDE_WAVES")) : 512;
-    const int wgrid = std::min(e->slots.n_slots, std::max(std::min(nw, e->slots.n_slots), nq > 0 ? side_waves : 1));
+    const int wgrid = std::min(e->side_slots, std::max(std::min(nw, e->side_slots), nq > 0 ? side_waves : 1));
     if (nw > 0 || nq > 0)
       hipLaunchKernelGGL(k_replan, dim3(wgrid), dim3(64), 0, st, d, P, e->slots, rl, e->replan_list[4], e->dist_rank,
                          e->dist_world, e->dist_world > 1 ? e->owned_list : nullptr, 15 & ~quad_mask, e->replan_list[5], qgrid, nq);
@@ -195,6 +199,7 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   while (replan_pending(e->hint + 8) > 0) {
     const int n = replan_pending(e->hint + 8);
     const int grid = std::min(n, e->slots.n_slots);
+    if (grid > e->side_slots && e->quad_on) { rc = arena_to_waves(e); if (rc) return rc; }
     const int w_rank = split_done ? 0 : e->dist_rank, w_world = split_done ? 1 : e->dist_world;
     split_done = true;
     LAUNCH(e, PK_REPLAN, n, k_replan, dim3(grid), dim3(64), d, P, e->slots, rl, e->replan_list[4], w_rank, w_world,
