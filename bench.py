@@ -322,9 +322,11 @@ def main():
         # the expansion rate is this run's own.  Peaks (MI355X_MICROARCH.md, Execution model): a SIMD issues one wave64 vector
         # instruction every 2 cycles -> 256 CUs x 4 SIMDs x 2.4 GHz / 2; one scalar unit per CU, one instruction per cycle.
         issue = None
-        sq_path = os.path.join(ROOT, "profiles", "r03_sq_replan_4096.json")
+        quads = os.environ.get("TS_QUAD", "1") != "0" and world == 1       # (the engine's default: k_replan_quad takes the big queues)
+        sq_path = os.path.join(ROOT, "profiles", "r03_sq_replan_quad_4096.json" if quads else "r03_sq_replan_4096.json")
         if dom == "k_decide_replan" and os.path.exists(sq_path):
-            sq = json.load(open(sq_path)).get("k_replan", {}).get("per_expansion")
+            sqj = json.load(open(sq_path))
+            sq = (sqj.get("both") or sqj.get("k_replan", {})).get("per_expansion")
             if sq:
                 rate = unit_note["expansions_per_s_in_kernel"]
                 valu_peak, salu_peak = 256 * 4 * 2.4e9 / 2, 256 * 2.4e9
@@ -335,7 +337,7 @@ def main():
                          "valu": {"per_expansion": sq["SQ_INSTS_VALU"], "achieved": sq["SQ_INSTS_VALU"] * rate / 1e9, "peak": valu_peak / 1e9, "frac": fv},
                          "salu": {"per_expansion": sq["SQ_INSTS_SALU"], "achieved": sq["SQ_INSTS_SALU"] * rate / 1e9, "peak": salu_peak / 1e9, "frac": fs},
                          "lds_per_expansion": sq.get("SQ_INSTS_LDS"), "vmem_per_expansion": sq.get("SQ_INSTS_VMEM_RD", 0) + sq.get("SQ_INSTS_VMEM_WR", 0),
-                         "source": "profiles/r03_sq_replan_4096.json (instructions per expansion) x this run's expansions/s; "
+                         "source": os.path.relpath(sq_path, ROOT) + " (instructions per expansion, all replanning kernels of the same command) x this run's expansions/s; "
                                    "peaks: 1 vector instruction / 2 cycles / SIMD, 1 scalar instruction / cycle / CU at 2.4 GHz"}
         host_keys = [k for k in prof if k.startswith("host_")]
         out = {
@@ -368,7 +370,7 @@ def main():
                 "warmup_seconds": warm_s,
             },
             "roofline": dict({
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": dom + (" (= k_replan_quad with k_replan beside it on the replanning waves, k_replan alone on the other ticks)" if dom == "k_decide_replan" and quads else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": avg_launch_s * 1e6,
                 "launches": launches}, **unit_note),
             "roofline_issue": issue,

@@ -47,7 +47,25 @@ def main():
             print(f"{short(r[0]):24s} calls {r[1]:5d} avg {r[3] / 1e3:9.2f} us  total {r[2] / 1e6:8.2f} ms")
         # "k_name:N first_leg_calls": the bench line's HIP-event figure covers the timed region only - the last N of the
         # kernel's launches in the first (headline) leg of the traced process; the trace also holds its warm-up launches
-        for spec in sys.argv[4:]:
+        # "replan_regions:N": the replanning phase of a tick is one k_replan launch, or - on a replanning wave - k_replan_quad
+        # with a k_replan launch running beside it: one region per tick = the union of the launches that overlap; the last N
+        # regions are the bench's timed ticks (its HIP events bracket exactly these regions)
+        for spec in [x for x in sys.argv[4:] if x.startswith("replan_regions:")]:
+            n = int(spec.split(":")[1])
+            rows2 = c.execute("select name, start, end from kernels where name like '%k_replan(%' or name like '%k_replan_quad(%' order by start").fetchall()
+            regions = []
+            for name, st_, en_ in rows2:
+                if regions and st_ < regions[-1][1]:
+                    regions[-1][1] = max(regions[-1][1], en_); regions[-1][2] += 1
+                else:
+                    regions.append([st_, en_, 1])
+            last = [r[1] - r[0] for r in regions[-n:]]
+            with open(sys.argv[3], "a", newline="") as f:
+                csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerow(
+                    [f"replanning regions (k_replan_quad + k_replan beside it, or k_replan alone) [last {len(last)} = the timed ticks]", len(last), sum(last),
+                     round(sum(last) / max(len(last), 1), 3), "", min(last), max(last)])
+            print(f"replanning regions: last {len(last)} avg {sum(last) / max(len(last), 1) / 1e3:.2f} us (of {len(regions)} regions, {sum(1 for r in regions if r[2] > 1)} with two kernels)")
+        for spec in [x for x in sys.argv[4:] if not x.startswith("replan_regions:")]:
             kname, n = spec.split(":")
             # (exactly this kernel: `k_replan(`, not k_replan_keys / k_replan_export)
             durs = [r[0] for r in c.execute("select duration from kernels where name like ? order by start", (f"%{kname}(%",)).fetchall()]
@@ -63,15 +81,17 @@ def main():
         fv, wv = f.get(k, []), w.get(k, [])
         out[k] = dict(launches=len(fv), fetch_kb_avg=sum(fv) / max(len(fv), 1), fetch_kb_max=max(fv) if fv else 0.0,
                       write_kb_avg=sum(wv) / max(len(wv), 1), write_kb_max=max(wv) if wv else 0.0)
-    if len(sys.argv) > 5:      # round-2 layout: bench.py reads `kernels` when `command_config` = [size, vehicles, policy] matches its run
-        size, vehicles, policy = sys.argv[5].split(",")
-        out = {"command": "python3 bench.py --no-cpu-baseline (full-policy leg + the config2 / lights secondary legs, one process)",
-               "command_config": [int(size), int(vehicles), policy],
+    if len(sys.argv) > 5:      # bench.py reads `kernels` when `command_config` = [size, vehicles, policy, steps, warmup] matches its run
+        size, vehicles, policy, steps, warmup = sys.argv[5].split(",")
+        out = {"command": f"python3 bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline (full-policy leg + the config2 / lights secondary legs, one process)",
+               "command_config": [int(size), int(vehicles), policy, int(steps), int(warmup)],
                "note": "KB per launch as rocprofv3 reports them; bench.py doubles FETCH_SIZE (gfx950: 128-B requests tallied at 64 B)",
                "kernels": out}
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     out = out.get("kernels", out)
-    print(json.dumps({k: v for k, v in out.items() if k.startswith("k_move") or k.startswith("k_decide")}, indent=1))
+    # k_decide_replan = the replanning phase as bench.py names it: k_replan + k_replan_quad launches (per LAUNCH REGION the
+    # bench divides by the ticks; here the per-launch averages of each kernel are kept, and their sum over the process)
+    print(json.dumps({k: v for k, v in out.items() if k.startswith("k_move") or k.startswith("k_decide") or k.startswith("k_replan")}, indent=1))
 
 
 if __name__ == "__main__":
