@@ -317,6 +317,9 @@ def main():
             if pj.get("command_config") == [args.size, args.vehicles, args.policy, args.steps, args.warmup] and pname in pj.get("kernels", {}):
                 pk = pj["kernels"][pname]
                 traffic = (2.0 * pk["fetch_kb_avg"] + pk["write_kb_avg"]) * 1024.0
+                pq = pj["kernels"].get("k_replan_quad")
+                if pname == "k_replan" and pq:     # a replanning wave's region = k_replan_quad + one k_replan launch beside it
+                    traffic += (2.0 * pq["fetch_kb_avg"] + pq["write_kb_avg"]) * 1024.0 * pq["launches"] / max(launches, 1)
         # Second roofline for the replanning kernel: instruction issue.  Instructions per expansion come from the SQ counter
         # passes committed under profiles/ (rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU ... on this build at this size),
         # the expansion rate is this run's own.  Peaks (MI355X_MICROARCH.md, Execution model): a SIMD issues one wave64 vector
