@@ -222,6 +222,7 @@ typedef struct TsTrafficTables {
   const int32_t* blk_service_off;       /* [n_blocks+1] CityBlock.get_service_road_cell's ranked candidates */
   const int32_t* blk_service_xy;        /*   (city_block.py:152-190: static; ties in CPython set order, so the
                                              list is an input recorded from the interpreter, not recomputed) */
+  int32_t statistics_update_interval;   /* STATISTICS_UPDATE_INTERVAL = 20 (config.py:428); 0 = 20 */
 } TsTrafficTables;
 
 /* dynamic_traffic_generator.py:102-131 counters that the hot path writes. */
@@ -242,6 +243,28 @@ typedef struct TsCounters {
   int64_t created_internal, created_through; /* DynamicTrafficAgent.created_* (reset at day rollover) */
   int64_t created_service_food, created_service_waste, live_service_food, live_service_waste;
 } TsCounters;
+
+/* DynamicTrafficAgent._update_cached_stats (dynamic_traffic_generator.py:525-648): what the generator gathers every
+ * STATISTICS_UPDATE_INTERVAL ticks INSIDE its own step - at its place in the shuffled order, after that tick's spawns - and
+ * the statistics panel reads between updates (ui_modules/traffic_statistics.py:58-239).  The sums over the scheduled vehicles
+ * are raw here (a device reduction at the generator's sync point of the move phase); the facade forms the reference's
+ * quotients and keys from them (mesa_api: cached_stats).  index 0..3 = internal, through, service_food, service_waste. */
+typedef struct TsCachedStats {
+  int32_t valid;                 /* 0 until the first update: the reference's dict is empty until then */
+  int32_t pad_;
+  int64_t update_step;           /* CityModel.step_count of the tick whose generator step took the snapshot (0-based) */
+  double dur_live[2];            /* sum of (elapsed - depart_time) over scheduled vehicles of population internal / through */
+  int64_t dist_live[2], n_live[2];   /* sum of steps_traveled, number of them */
+  int64_t stuck_ticks_sum, stuck_ticks_max;   /* over the scheduled vehicles with is_stuck */
+  int64_t stuck, collisions, malfunctions, parked, overtaking, in_stuck_detour;   /* the generator's counters at that moment */
+  int64_t live_internal, live_through, live_service_food, live_service_waste;
+  int64_t count_completed[2], total_distance[2];
+  double total_duration[2];
+  int64_t daily_total[4], created[4], errored[4];
+  double eta[4];                 /* next_service_eta(kind), NaN = None */
+  double avg_daily_difference;
+} TsCachedStats;
+int ts_cached_stats(ts_handle h, TsCachedStats* out);
 
 /* One row per live vehicle, in `active_vehicle_agents` order (city_model.py:1903). */
 enum {

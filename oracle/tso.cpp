@@ -175,7 +175,7 @@ struct Group {
   int ns_pressure = 0, ew_pressure = 0;
 };
 
-struct Trip { int origin, dest; double depart; int kind; };  // kind: TS_POP_INTERNAL / TS_POP_THROUGH / TS_TRIP_SERVICE_*
+struct Trip { int origin, dest; double depart; int kind; int day; };  // kind: TS_POP_INTERNAL / TS_POP_THROUGH / TS_TRIP_SERVICE_*; day: pending_by_day's key
 struct Block {   // CityBlock (city_block.py:39-77)
   int cells = 0;
   bool needs_food = false, produces_waste = false;
@@ -195,6 +195,11 @@ struct Generator {
   std::vector<int> hw_in, hw_out;
   std::vector<Trip> pending;
   int current_day = 0;
+  // _update_cached_stats (dynamic_traffic_generator.py:525-648) and what feeds it
+  std::vector<long long> daily_difference_history;     // (165-167)
+  long long completed_at_day_start = 0;                // count_completed_internal + _through when the day began: daily_finished_* = now - this
+  int ticks_since_stats = 0;
+  TsCachedStats cs{};
 };
 
 struct Rain {     // RainAgent (rain.py:18-84)
@@ -1246,7 +1251,7 @@ void generate_day(E* e, int day_idx) {
         int db = dests[e->rng_global.randbelow((uint32_t)dests.size())];
         int oc = G.blk_entr[ob][e->rng_global.randbelow((uint32_t)G.blk_entr[ob].size())];
         int dc = G.blk_entr[db][e->rng_global.randbelow((uint32_t)G.blk_entr[db].size())];
-        G.pending.push_back(Trip{oc, dc, t, TS_POP_INTERNAL});
+        G.pending.push_back(Trip{oc, dc, t, TS_POP_INTERNAL, day_idx});
       }
     }
     // service vehicles, uniform per zone (362-376): one entrance draw per trip
@@ -1254,12 +1259,12 @@ void generate_day(E* e, int day_idx) {
     for (int j = 1; j <= Nf; j++) {
       double t = z0 + (double)((long long)j * (long long)span) / (double)(Nf + 1);
       int sc = G.hw_in[e->rng_global.randbelow((uint32_t)G.hw_in.size())];
-      G.pending.push_back(Trip{sc, -1, t, TS_TRIP_SERVICE_FOOD});
+      G.pending.push_back(Trip{sc, -1, t, TS_TRIP_SERVICE_FOOD, day_idx});
     }
     for (int j = 1; j <= Nw; j++) {
       double t = z0 + (double)((long long)j * (long long)span) / (double)(Nw + 1);
       int sc = G.hw_in[e->rng_global.randbelow((uint32_t)G.hw_in.size())];
-      G.pending.push_back(Trip{sc, -1, t, TS_TRIP_SERVICE_WASTE});
+      G.pending.push_back(Trip{sc, -1, t, TS_TRIP_SERVICE_WASTE, day_idx});
     }
     long long thr = (long long)std::nearbyint((double)G.T.passing_population_per_day * z.through_distribution);
     thr -= Nf + Nw;   // SERVICE_VEHICLES_COUNT_AS_THROUGH defaults to True (90, 381-382)
@@ -1268,7 +1273,7 @@ void generate_day(E* e, int day_idx) {
       double t = z0 + e->rng_global.random() * span;
       int ent = G.hw_in[e->rng_global.randbelow((uint32_t)G.hw_in.size())];
       int ex = G.hw_out[e->rng_global.randbelow((uint32_t)G.hw_out.size())];
-      G.pending.push_back(Trip{ent, ex, t, TS_POP_THROUGH});
+      G.pending.push_back(Trip{ent, ex, t, TS_POP_THROUGH, day_idx});
     }
   }
 }
@@ -1327,6 +1332,47 @@ void spawn_service(E* e, const Trip& t) {
   spawn_service_at(e, t.origin, t.kind, id);
 }
 
+// DynamicTrafficAgent._update_cached_stats (dynamic_traffic_generator.py:525-648): the sums over city.schedule.agents as they
+// are at this point of the shuffled order, the counters, and the daily figures (pending_trips_today 244-248, next_service_eta 278-288)
+void update_cached_stats(E* e) {
+  Generator& G = e->gen;
+  TsCachedStats& c = G.cs;
+  memset(&c, 0, sizeof(c));
+  c.valid = 1;
+  c.update_step = e->C.step_count;
+  for (const Vehicle& v : e->veh) {
+    if (!v.alive) continue;
+    const int k = v.pop_type == TS_POP_INTERNAL ? 0 : v.pop_type == TS_POP_THROUGH ? 1 : -1;
+    if (k >= 0) { c.dur_live[k] += e->C.elapsed - v.depart_time; c.dist_live[k] += v.steps_traveled; c.n_live[k]++; }
+    if (v.is_stuck) { c.stuck_ticks_sum += v.stuck_ticks; c.stuck_ticks_max = std::max<int64_t>(c.stuck_ticks_max, v.stuck_ticks); }
+  }
+  c.stuck = e->C.stuck; c.collisions = e->C.collisions; c.malfunctions = e->C.malfunctions; c.parked = e->C.parked;
+  c.overtaking = e->C.overtaking; c.in_stuck_detour = e->C.in_stuck_detour;
+  c.live_internal = e->C.live_internal; c.live_through = e->C.live_through;
+  c.live_service_food = e->C.live_service_food; c.live_service_waste = e->C.live_service_waste;
+  c.count_completed[0] = e->C.count_completed_internal; c.count_completed[1] = e->C.count_completed_through;
+  c.total_distance[0] = e->C.total_distance_internal; c.total_distance[1] = e->C.total_distance_through;
+  c.total_duration[0] = e->C.total_duration_internal; c.total_duration[1] = e->C.total_duration_through;
+  const int kinds[4] = {TS_POP_INTERNAL, TS_POP_THROUGH, TS_TRIP_SERVICE_FOOD, TS_TRIP_SERVICE_WASTE};
+  const int64_t created[4] = {e->C.created_internal, e->C.created_through, e->C.created_service_food, e->C.created_service_waste};
+  for (int q = 0; q < 4; q++) {
+    long long pending_today = 0;
+    double eta = std::numeric_limits<double>::quiet_NaN();
+    for (const Trip& t : G.pending) {
+      if (t.day != G.current_day || t.kind != kinds[q]) continue;
+      pending_today++;
+      if (t.depart > e->C.elapsed) { const double dt = t.depart - e->C.elapsed; if (!(eta <= dt)) eta = dt; }
+    }
+    c.created[q] = created[q];
+    c.daily_total[q] = q == 0 ? G.T.internal_population_per_day : q == 1 ? G.T.passing_population_per_day : created[q] + pending_today;
+    c.eta[q] = eta;
+  }
+  c.errored[0] = e->C.errored_internal; c.errored[1] = e->C.errored_through;
+  double sum = 0.0;
+  for (long long x : G.daily_difference_history) sum += (double)x;
+  c.avg_daily_difference = G.daily_difference_history.empty() ? 0.0 : sum / (double)G.daily_difference_history.size();
+}
+
 // DynamicTrafficAgent.step (dynamic_traffic_generator.py:153-194) + _spawn (398-416)
 void generator_step(E* e) {
   Generator& G = e->gen;
@@ -1335,6 +1381,9 @@ void generator_step(E* e) {
   const double total_secs = G.T.start_offset_seconds + e->C.elapsed;
   const int new_day = (int)std::floor(total_secs / 86400.0);
   if (new_day > G.current_day) {
+    const long long done = e->C.count_completed_internal + e->C.count_completed_through;
+    G.daily_difference_history.push_back((done - G.completed_at_day_start) - (e->C.created_internal + e->C.created_through));   // finished - spawned (165-167)
+    G.completed_at_day_start = done;
     for (int dd = G.current_day + 1; dd <= new_day; dd++) generate_day(e, dd);
     G.current_day = new_day;
     e->C.created_internal = 0; e->C.created_through = 0;
@@ -1352,6 +1401,9 @@ void generator_step(E* e) {
     tso_add_vehicles(e, 1, s, g, &pop, nullptr, nullptr);
   }
   G.pending.swap(keep);
+  // _update_cached_stats every STATISTICS_UPDATE_INTERVAL ticks, inside this step (188-194)
+  const int interval = G.T.statistics_update_interval > 0 ? G.T.statistics_update_interval : 20;
+  if (++G.ticks_since_stats >= interval) { update_cached_stats(e); G.ticks_since_stats = 0; }
 }
 
 // ------------------------------ one tick (city_model.py:1831-1860) -----------------------------
@@ -1913,6 +1965,11 @@ int tso_astar(ts_handle e, int32_t sx, int32_t sy, int32_t gx, int32_t gy, int32
 
 int tso_set_device(int32_t) { return TS_OK; }
 // (the checker is a single sequential process: there is nothing to shard)
+int tso_cached_stats(ts_handle e, TsCachedStats* out) {
+  if (!e || !out) return TS_E_INVALID;
+  *out = e->gen.cs;
+  return TS_OK;
+}
 int tso_set_replan_sharding(ts_handle, int32_t, int32_t world, ts_exchange_fn, void*) { return world == 1 ? TS_OK : TS_E_UNSUPPORTED; }
 int tso_set_replan_sharding_device(ts_handle, int32_t, int32_t world, ts_exchange_fn, void*) { return world == 1 ? TS_OK : TS_E_UNSUPPORTED; }
 int tso_profile_enable(ts_handle, int32_t) { return TS_OK; }

@@ -350,7 +350,7 @@ def none_i(v):
     return -1 if v is None else int(v)
 
 
-def run_scenario(name):
+def run_scenario(name, stats_only=False):
     import numpy as np
     spec = SCENARIOS[name]
     _setup_paths()
@@ -477,6 +477,7 @@ def run_scenario(name):
     dta = getattr(m, "dynamic_traffic_generator", None)
     dens_ticks = {}
     raised = None
+    stats_rows = []
     for t in range(T):
         c0 = calls["n"]
         try:
@@ -486,6 +487,11 @@ def run_scenario(name):
             T = t
             break
         astar_per_tick.append(calls["n"] - c0)
+        if stats_only:      # DynamicTrafficAgent.cached_stats as the statistics panel reads it, whenever it changed
+            snap = {k: (None if v is None else float(v) if isinstance(v, float) else int(v)) for k, v in dta.cached_stats.items()}
+            if not stats_rows or snap != stats_rows[-1][1]:
+                stats_rows.append([t, snap])
+            continue
         occ_t.append(np.packbits(m.occupancy_map.astype(np.uint8).ravel()))
         stop_t.append(np.packbits(m.stop_map.astype(np.uint8).ravel()))
         stuck_t.append(np.packbits(m.stuck_map.astype(np.uint8).ravel()))
@@ -507,6 +513,11 @@ def run_scenario(name):
         nsched.append(len(m.schedule._agents))
         if t in (0, spec["ticks"] // 2):
             dens_ticks[t] = m.density_map32.copy()
+    if stats_only:
+        path = os.path.join(HERE, f"cached_stats_{name}.json")
+        json.dump(dict(scenario=name, ticks=T, interval=int(Defaults.STATISTICS_UPDATE_INTERVAL), rows=stats_rows), open(path, "w"), indent=0)
+        print(f"[{name}] cached_stats snapshots={len(stats_rows)} keys={len(stats_rows[-1][1]) if stats_rows else 0} -> {path}")
+        return
     out["occ_t"] = np.stack(occ_t)
     out["stop_t"] = np.stack(stop_t)
     out["stuck_t"] = np.stack(stuck_t)
@@ -795,6 +806,8 @@ def main():
         run_astar_fov_kats()
     elif what == "worlds":
         run_worlds()
+    elif what == "stats":      # `make_golden.py stats <scenario>`: cached_stats_<scenario>.json only, the trace is left alone
+        run_scenario(sys.argv[2], stats_only=True)
     else:
         run_scenario(what)
 

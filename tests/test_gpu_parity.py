@@ -427,3 +427,13 @@ def test_hip_quad_and_wave_searchers_share_the_table_arena(monkeypatch):
     h, c = _pair_full(768, 30_000, 3)
     ch = _compare_full(h, c, 9, every=1)
     assert ch.astar_calls > 20_000
+
+
+@pytest.mark.parametrize("name", ["dta_64_s12", "dta_96_s13", "config1_64_s11"])
+def test_hip_cached_stats_match_the_reference(hip, name):
+    """DynamicTrafficAgent._update_cached_stats on the device (k_live_stats at the generator's place in the shuffled order,
+    every STATISTICS_UPDATE_INTERVAL ticks) + the host-side daily keys: every key of the reference's dict, every tick."""
+    from tests.trace_util import replay_and_compare_cached_stats
+    tr = load_trace(trace_path(name))
+    setup_from_trace(hip, tr, explicit_paths=False)
+    assert replay_and_compare_cached_stats(hip, tr, name) >= 9

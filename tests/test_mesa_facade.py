@@ -320,3 +320,18 @@ def test_remove_vehicle_counts_the_callers_population_type(oracle):
     c3 = m.engine.counters()
     assert (c3.live_internal, c3.live_through) == (c0.live_internal - 1, c0.live_through - 1)
     assert len(m.active_vehicle_agents) == len([v for v in m.active_vehicle_agents])
+
+
+def test_facade_cached_stats_keys_over_oracle(oracle):
+    """model.dynamic_traffic_generator.cached_stats carries what ui_modules/traffic_statistics.py:122-150 reads."""
+    import json
+    tr = load_trace(trace_path("dta_64_s12"))
+    m = CityModel(64, 64, seed=11, defaults=tr["defaults_json"], engine=oracle, traffic=json.loads(str(tr["dta_params"])))
+    assert m.dynamic_traffic_generator.cached_stats == {}
+    for _ in range(25):
+        m.step()
+    cs = m.dynamic_traffic_generator.cached_stats
+    for k in ("daily_total_internal", "remaining_through", "percentage_created_internal", "eta_service_food", "avg_duration_through_live",
+              "avg_time_per_unit_internal_total", "live_average_stuck_duration", "live_max_stuck_duration", "avg_daily_difference"):
+        assert k in cs
+    assert cs["daily_total_internal"] == json.loads(str(tr["dta_params"]))["P_int"] and cs["eta_service_food"] is None

@@ -17,3 +17,11 @@ def test_oracle_reproduces_reference_trace(oracle, name):
     # the A* call count per tick is part of the contract too (replan policy, A10/A12)
     if "raised_at_tick" not in tr:   # (the tick in which the reference raised ran part of its searches)
         assert oracle.counters().astar_calls == int(tr["astar_calls_spawn"]) + int(tr["astar_per_tick"].sum())
+
+
+@pytest.mark.parametrize("name", ["dta_64_s12", "dta_96_s13", "config1_64_s11"])
+def test_oracle_cached_stats_match_the_reference(oracle, name):
+    from tests.trace_util import replay_and_compare_cached_stats
+    tr = load_trace(trace_path(name))
+    setup_from_trace(oracle, tr)
+    assert replay_and_compare_cached_stats(oracle, tr, name) >= 9

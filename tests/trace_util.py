@@ -133,3 +133,29 @@ def replay_and_compare(api, tr, ticks=None, check_rng=True, check_counters=True)
         else:
             raise AssertionError(f"tick {T}: the reference raised ({tr['raised_message']}), the engine did not")
     return T
+
+
+STATS_TRACES = ["dta_64_s12", "dta_96_s13", "config1_64_s11"]
+
+
+def replay_and_compare_cached_stats(api, tr, name):
+    """DynamicTrafficAgent.cached_stats (dynamic_traffic_generator.py:525-648) against tests/golden/cached_stats_<name>.json,
+    captured from the reference tick by tick (`make_golden.py stats <name>`): the dict as the statistics panel would read it
+    after every tick - empty until the generator's first update, then refreshed every STATISTICS_UPDATE_INTERVAL ticks inside
+    the generator's own step, i.e. half-way through a tick's shuffled order.  Every key, exact values."""
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(trace_path(name)), f"cached_stats_{name}.json")))
+    rows = {int(t): snap for t, snap in gold["rows"]}
+    want = {}
+    n_checked = 0
+    for t in range(int(gold["ticks"])):
+        api.step(1)
+        if t in rows:
+            want = rows[t]
+        got = api.cached_stats()
+        assert set(got) == set(want), f"tick {t}: keys differ: {sorted(set(got) ^ set(want))}"
+        for k, v in want.items():
+            assert got[k] == v, f"tick {t}: cached_stats[{k!r}] = {got[k]!r}, the reference has {v!r}"
+        n_checked += 1 if want else 0
+    assert n_checked > 0 and len(rows) > 1
+    return len(rows)

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import zlib
-from typing import Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 
@@ -113,7 +113,22 @@ class TsTrafficTables(C.Structure):
                 ("needs_food_type_mask", C.c_int32), ("produces_waste_type_mask", C.c_int32),
                 ("service_max_load_food", C.c_double), ("service_max_load_waste", C.c_double),
                 ("food_capacity_per_cell", C.c_double), ("waste_capacity_per_cell", C.c_double),
-                ("blk_inner_cells", C.c_void_p), ("blk_service_off", C.c_void_p), ("blk_service_xy", C.c_void_p)]
+                ("blk_inner_cells", C.c_void_p), ("blk_service_off", C.c_void_p), ("blk_service_xy", C.c_void_p),
+                ("statistics_update_interval", C.c_int32)]
+
+
+class TsCachedStats(C.Structure):
+    """include/trafficsim.h: DynamicTrafficAgent._update_cached_stats' raw figures (index 0..3 = internal, through,
+    service_food, service_waste)."""
+    _fields_ = [("valid", C.c_int32), ("pad_", C.c_int32), ("update_step", C.c_int64),
+                ("dur_live", C.c_double * 2), ("dist_live", C.c_int64 * 2), ("n_live", C.c_int64 * 2),
+                ("stuck_ticks_sum", C.c_int64), ("stuck_ticks_max", C.c_int64),
+                ("stuck", C.c_int64), ("collisions", C.c_int64), ("malfunctions", C.c_int64), ("parked", C.c_int64),
+                ("overtaking", C.c_int64), ("in_stuck_detour", C.c_int64),
+                ("live_internal", C.c_int64), ("live_through", C.c_int64), ("live_service_food", C.c_int64), ("live_service_waste", C.c_int64),
+                ("count_completed", C.c_int64 * 2), ("total_distance", C.c_int64 * 2), ("total_duration", C.c_double * 2),
+                ("daily_total", C.c_int64 * 4), ("created", C.c_int64 * 4), ("errored", C.c_int64 * 4),
+                ("eta", C.c_double * 4), ("avg_daily_difference", C.c_double)]
 
 
 # Defaults.TIME_ZONES (config.py:155-236) with block types as indices into AVAILABLE_CITY_BLOCKS
@@ -221,6 +236,7 @@ class CApi:
         f("set_lights").argtypes = [C.c_void_p, C.POINTER(TsLightTables)]
         f("schedule_add").argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         f("set_traffic_generator").argtypes = [C.c_void_p, C.POINTER(TsTrafficTables)]
+        f("cached_stats").argtypes = [C.c_void_p, C.POINTER(TsCachedStats)]
         f("seed").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32]
         f("seed_int").argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
         f("rng_state").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_uint32)]
@@ -332,8 +348,52 @@ class CApi:
         self._chk(self._f("set_lights")(self.h, C.byref(t)))
         self.n_groups = t.n_groups
 
+    def cached_stats(self) -> Dict[str, object]:
+        """DynamicTrafficAgent.cached_stats as the statistics panel reads it (ui_modules/traffic_statistics.py): the
+        reference's keys and quotients (dynamic_traffic_generator.py:562-648) formed from ts_cached_stats' raw figures;
+        {} until the generator's first update, like the reference's dict."""
+        c = TsCachedStats()
+        self._chk(self._f("cached_stats")(self.h, C.byref(c)))
+        if not c.valid:
+            return {}
+
+        def safe(a, b):
+            return a / b if b else 0.0
+        out: Dict[str, object] = {}
+        names = ("internal", "through")
+        for what, num_c, num_l, den_c, den_l in (
+                ("avg_duration", c.total_duration, c.dur_live, c.count_completed, c.n_live),
+                ("avg_time_per_unit", c.total_duration, c.dur_live, c.total_distance, c.dist_live)):
+            for k, nm in enumerate(names):
+                out[f"{what}_{nm}_completed"] = safe(num_c[k], den_c[k])
+            for k, nm in enumerate(names):
+                out[f"{what}_{nm}_live"] = safe(num_l[k], den_l[k])
+            for k, nm in enumerate(names):
+                out[f"{what}_{nm}_total"] = safe(num_c[k] + num_l[k], den_c[k] + den_l[k])
+        for what in ("avg_duration", "avg_time_per_unit"):
+            for nm in names:
+                out[f"{what}_{nm}"] = out[f"{what}_{nm}_total"]
+        out["avg_daily_difference"] = c.avg_daily_difference
+        out["count_completed_internal"] = int(c.count_completed[0])
+        for f in ("live_internal", "live_through", "live_service_food", "live_service_waste", "collisions", "malfunctions", "parked",
+                  "overtaking", "stuck"):
+            out[f] = int(getattr(c, f))
+        out["live_average_stuck_duration"] = (c.stuck_ticks_sum / c.stuck) if c.stuck > 0 else 0.0
+        out["live_max_stuck_duration"] = int(c.stuck_ticks_max)
+        out["in_stuck_detour"] = int(c.in_stuck_detour)
+        for k, kind in enumerate(("internal", "through", "service_food", "service_waste")):
+            total, created = int(c.daily_total[k]), int(c.created[k])
+            out[f"daily_total_{kind}"] = total
+            out[f"created_{kind}"] = created
+            out[f"remaining_{kind}"] = total - created
+            out[f"percentage_created_{kind}"] = (created / total * 100) if total else 0.0
+            out[f"errored_{kind}"] = int(c.errored[k]) if k < 2 else 0.0      # (getattr(self, "errored_service_*", 0.0): no such attribute)
+            out[f"eta_{kind}"] = None if c.eta[k] != c.eta[k] else float(c.eta[k])
+        return out
+
     def set_traffic_generator(self, tables: dict, internal_per_day=10000, passing_per_day=2400,
-                              start_offset_seconds=6 * 3600, zones=None, service: Optional[dict] = None):
+                              start_offset_seconds=6 * 3600, zones=None, service: Optional[dict] = None,
+                              statistics_update_interval: int = 20):
         """DynamicTrafficAgent.__init__: `tables` carries blk_type / blk_entr_off / blk_entr_xy /
         highway_entrances_xy / highway_exits_xy (golden world-table keys).  Generates day 0 (global stream)."""
         t = TsTrafficTables()
@@ -347,6 +407,7 @@ class CApi:
         t.highway_exits_xy = keep["ho"].ctypes.data
         t.internal_population_per_day, t.passing_population_per_day = int(internal_per_day), int(passing_per_day)
         t.start_offset_seconds = int(start_offset_seconds)
+        t.statistics_update_interval = int(statistics_update_interval)
         zs = zones if zones is not None else DEFAULT_TIME_ZONES
         t.n_zones = len(zs)
         for i, (h0, h1, thr, pairs) in enumerate(zs):

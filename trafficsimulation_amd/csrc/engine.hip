@@ -1894,6 +1894,12 @@ int ts_counters(ts_handle e, TsCounters* out) {
   return TS_OK;
 }
 
+int ts_cached_stats(ts_handle e, TsCachedStats* out) {
+  if (!e || !out) return TS_E_INVALID;
+  *out = e->gen.cs;
+  return TS_OK;
+}
+
 int ts_set_replan_sharding(ts_handle e, int32_t rank, int32_t world, ts_exchange_fn fn, void* user) {
   if (!e || world < 1 || rank < 0 || rank >= world) return TS_E_INVALID;
   if (world > 1 && !fn) return fail(e, TS_E_INVALID, "sharded replans need an exchange callback");

@@ -162,7 +162,7 @@ void generate_day(E* e, int day_idx) {
         const int db = dests[r.randbelow((uint32_t)dests.size())];
         const int oc = G.blk_entr[ob][r.randbelow((uint32_t)G.blk_entr[ob].size())];
         const int dc = G.blk_entr[db][r.randbelow((uint32_t)G.blk_entr[db].size())];
-        G.pending.push_back(ts_engine::Trip{oc, dc, t, TS_POP_INTERNAL});
+        G.pending.push_back(ts_engine::Trip{oc, dc, t, TS_POP_INTERNAL, day_idx});
       }
     }
     // service vehicles, uniform per zone (362-376): one entrance draw per trip
@@ -170,12 +170,12 @@ void generate_day(E* e, int day_idx) {
     for (int j = 1; j <= Nf; j++) {
       const double t = z0 + (double)((long long)j * (long long)span) / (double)(Nf + 1);
       const int sc = G.hw_in[r.randbelow((uint32_t)G.hw_in.size())];
-      G.pending.push_back(ts_engine::Trip{sc, -1, t, TS_TRIP_SERVICE_FOOD});
+      G.pending.push_back(ts_engine::Trip{sc, -1, t, TS_TRIP_SERVICE_FOOD, day_idx});
     }
     for (int j = 1; j <= Nw; j++) {
       const double t = z0 + (double)((long long)j * (long long)span) / (double)(Nw + 1);
       const int sc = G.hw_in[r.randbelow((uint32_t)G.hw_in.size())];
-      G.pending.push_back(ts_engine::Trip{sc, -1, t, TS_TRIP_SERVICE_WASTE});
+      G.pending.push_back(ts_engine::Trip{sc, -1, t, TS_TRIP_SERVICE_WASTE, day_idx});
     }
     long long thr = (long long)std::nearbyint((double)G.T.passing_population_per_day * z.through_distribution);
     thr -= Nf + Nw;   // SERVICE_VEHICLES_COUNT_AS_THROUGH defaults to True (90, 381-382)
@@ -183,7 +183,7 @@ void generate_day(E* e, int day_idx) {
       const double t = z0 + r.random() * span;
       const int ent = G.hw_in[r.randbelow((uint32_t)G.hw_in.size())];
       const int ex = G.hw_out[r.randbelow((uint32_t)G.hw_out.size())];
-      G.pending.push_back(ts_engine::Trip{ent, ex, t, TS_POP_THROUGH});
+      G.pending.push_back(ts_engine::Trip{ent, ex, t, TS_POP_THROUGH, day_idx});
     }
   }
 }
@@ -347,6 +347,58 @@ int spawn_service(E* e, const ts_engine::Trip& t) {
   return spawn_service_at(e, t.origin, t.kind, id);
 }
 
+// DynamicTrafficAgent._update_cached_stats (525-648).  The generator takes it inside its own step: the move phase has run
+// every lower-ranked agent on the device and none of the higher-ranked ones, the tick's spawns are placed - exactly the
+// `city.schedule.agents` the reference sums over.  The sums are a device reduction (k_live_stats), the counters come down
+// with them, the daily figures are host state (pending_trips_today 244-248, next_service_eta 278-288).
+int update_cached_stats(E* e) {
+  auto& G = e->gen;
+  Dev& d = e->d;
+  if (!e->d_live_stats) HIPOK(dalloc(e, &e->d_live_stats, 8));
+  HIPOK(hipMemsetAsync(e->d_live_stats, 0, 8 * sizeof(double), e->stream));
+  if (e->n_active > 0)
+    hipLaunchKernelGGL(k_live_stats, dim3(nblk(e->n_active)), dim3(BLK), 0, e->stream, d, e->n_active, e->C.elapsed, e->d_live_stats);
+  double raw[8];
+  HIPOK(hipMemcpyAsync(raw, e->d_live_stats, sizeof(raw), hipMemcpyDeviceToHost, e->stream));
+  int rc = sync_counters(e);
+  if (rc) return rc;
+  TsCachedStats& c = G.cs;
+  memset(&c, 0, sizeof(c));
+  c.valid = 1;
+  c.update_step = e->C.step_count;
+  long long li[8];
+  memcpy(li, raw, sizeof(li));
+  c.dur_live[0] = raw[0]; c.dur_live[1] = raw[1];
+  c.dist_live[0] = li[2]; c.dist_live[1] = li[3]; c.n_live[0] = li[4]; c.n_live[1] = li[5];
+  c.stuck_ticks_sum = li[6]; c.stuck_ticks_max = li[7];
+  c.stuck = e->C.stuck; c.collisions = e->C.collisions; c.malfunctions = e->C.malfunctions; c.parked = e->C.parked;
+  c.overtaking = e->C.overtaking; c.in_stuck_detour = e->C.in_stuck_detour;
+  c.live_internal = e->C.live_internal; c.live_through = e->C.live_through;
+  c.live_service_food = e->C.live_service_food; c.live_service_waste = e->C.live_service_waste;
+  c.count_completed[0] = e->C.count_completed_internal; c.count_completed[1] = e->C.count_completed_through;
+  c.total_distance[0] = e->C.total_distance_internal; c.total_distance[1] = e->C.total_distance_through;
+  c.total_duration[0] = e->C.total_duration_internal; c.total_duration[1] = e->C.total_duration_through;
+  const int kinds[4] = {TS_POP_INTERNAL, TS_POP_THROUGH, TS_TRIP_SERVICE_FOOD, TS_TRIP_SERVICE_WASTE};
+  const int64_t created[4] = {e->C.created_internal, e->C.created_through, e->C.created_service_food, e->C.created_service_waste};
+  for (int q = 0; q < 4; q++) {
+    long long pending_today = 0;
+    double eta = std::numeric_limits<double>::quiet_NaN();
+    for (const auto& t : G.pending) {
+      if (t.day != G.current_day || t.kind != kinds[q]) continue;
+      pending_today++;
+      if (t.depart > e->C.elapsed) { const double dt = t.depart - e->C.elapsed; if (!(eta <= dt)) eta = dt; }
+    }
+    c.created[q] = created[q];
+    c.daily_total[q] = q == 0 ? G.T.internal_population_per_day : q == 1 ? G.T.passing_population_per_day : created[q] + pending_today;
+    c.eta[q] = eta;
+  }
+  c.errored[0] = e->C.errored_internal; c.errored[1] = e->C.errored_through;
+  double sum = 0.0;
+  for (long long x : G.daily_difference_history) sum += (double)x;
+  c.avg_daily_difference = G.daily_difference_history.empty() ? 0.0 : sum / (double)G.daily_difference_history.size();
+  return TS_OK;
+}
+
 // DynamicTrafficAgent.step (153-194) and _spawn (398-416), executed at the agent's place in the shuffled order:
 // every lower-ranked agent has stepped on the device, every higher-ranked one has not yet.
 int generator_step(E* e) {
@@ -356,6 +408,11 @@ int generator_step(E* e) {
   const double total_secs = G.T.start_offset_seconds + e->C.elapsed;
   const int new_day = (int)std::floor(total_secs / 86400.0);
   if (new_day > G.current_day) {
+    int rc = sync_counters(e);      // (the completed counts live on the device)
+    if (rc) return rc;
+    const long long done = e->C.count_completed_internal + e->C.count_completed_through;
+    G.daily_difference_history.push_back((done - G.completed_at_day_start) - (e->C.created_internal + e->C.created_through));   // finished - spawned (165-167)
+    G.completed_at_day_start = done;
     for (int dd = G.current_day + 1; dd <= new_day; dd++) generate_day(e, dd);
     G.current_day = new_day;
     e->C.created_internal = 0; e->C.created_through = 0;
@@ -376,6 +433,9 @@ int generator_step(E* e) {
     int rc = add_vehicle_planned(e, t.origin, t.dest, t.kind);
     if (rc) return rc;
   }
+  // _update_cached_stats every STATISTICS_UPDATE_INTERVAL ticks, inside this step (188-194)
+  const int interval = G.T.statistics_update_interval > 0 ? G.T.statistics_update_interval : 20;
+  if (++G.ticks_since_stats >= interval) { int rc = update_cached_stats(e); if (rc) return rc; G.ticks_since_stats = 0; }
   return TS_OK;
 }
 

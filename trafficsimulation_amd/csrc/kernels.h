@@ -882,6 +882,41 @@ __global__ void k_decide_despawn(Dev d, TsParams P, int i_arrived, int i_skipped
   }
 }
 // CityModel.remove_vehicle called by the host between ticks (ts_remove_vehicle)
+// _update_cached_stats' loop over the scheduled vehicles (dynamic_traffic_generator.py:537-556): per population the sum of
+// (elapsed - depart_time), of steps_traveled and the count; over the stuck ones the sum and the maximum of stuck_ticks.  All
+// of it is integer-valued (depart times are multiples of the tick length), so the order of the additions cannot show.
+// out: [0..1] doubles, [2..7] the same words as int64 (dist x 2, n x 2, stuck sum, stuck max).
+__global__ void k_live_stats(Dev d, int n_active, double elapsed, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double dur[2] = {0.0, 0.0};
+  long long dist[2] = {0, 0}, cnt[2] = {0, 0}, ssum = 0, smax = 0;
+  if (i < n_active) {
+    const int vid = d.active[i];
+    if (vid >= 0 && (d.flags[vid] & VF_ALIVE)) {
+      const int pop = d.pop[vid];
+      const int k = pop == TS_POP_INTERNAL ? 0 : pop == TS_POP_THROUGH ? 1 : -1;
+      if (k >= 0) { dur[k] = elapsed - d.depart[vid]; dist[k] = d.steps[vid]; cnt[k] = 1; }
+      if (d.flags[vid] & VF_STUCK) { ssum = d.stuck_ticks[vid]; smax = ssum; }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int k = 0; k < 2; k++) {
+      dur[k] += __shfl_down(dur[k], o);
+      dist[k] += __shfl_down(dist[k], o);
+      cnt[k] += __shfl_down(cnt[k], o);
+    }
+    ssum += __shfl_down(ssum, o);
+    smax = max(smax, (long long)__shfl_down(smax, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* oi = reinterpret_cast<unsigned long long*>(out);
+    for (int k = 0; k < 2; k++) {
+      if (cnt[k]) { atomicAdd(&out[k], dur[k]); atomicAdd(&oi[2 + k], (unsigned long long)dist[k]); atomicAdd(&oi[4 + k], (unsigned long long)cnt[k]); }
+    }
+    if (ssum) atomicAdd(&oi[6], (unsigned long long)ssum);
+    if (smax) atomicMax(&oi[7], (unsigned long long)smax);
+  }
+}
 __global__ void k_remove_one(Dev d, int vid, int pop_arg) {
   if (threadIdx.x || blockIdx.x) return;
   uint16_t f = d.flags[vid];

@@ -568,9 +568,11 @@ class _TrafficStats:
         raise AttributeError(name)
 
     @property
-    def cached_stats(self) -> Dict[str, float]:
-        c = self._model._counters()
-        return {f: getattr(c, f) for f in _TrafficStats._FIELDS}
+    def cached_stats(self) -> Dict[str, object]:
+        """DynamicTrafficAgent.cached_stats (dynamic_traffic_generator.py:525-648): refreshed inside the generator's own step
+        every STATISTICS_UPDATE_INTERVAL ticks, read by ui_modules/traffic_statistics.py between updates; empty before the
+        first update, like the reference's."""
+        return self._model.engine.cached_stats()
 
 
 class _RainManager:
