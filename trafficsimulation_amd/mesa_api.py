@@ -571,8 +571,13 @@ class _TrafficStats:
     def cached_stats(self) -> Dict[str, object]:
         """DynamicTrafficAgent.cached_stats (dynamic_traffic_generator.py:525-648): refreshed inside the generator's own step
         every STATISTICS_UPDATE_INTERVAL ticks, read by ui_modules/traffic_statistics.py between updates; empty before the
-        first update, like the reference's."""
-        return self._model.engine.cached_stats()
+        first update, like the reference's.  A generator without any population to spawn is not stepped as an agent of
+        its own by the engine (nothing it does could be seen): its counters are served as they are then."""
+        cs = self._model.engine.cached_stats()
+        if cs or self._model._traffic_armed:
+            return cs
+        c = self._model._counters()
+        return {f: getattr(c, f) for f in _TrafficStats._FIELDS}
 
 
 class _RainManager:
@@ -674,6 +679,7 @@ class CityModel:
         # DynamicTrafficAgent("DTA", self) (city_model.py:203-204): traffic = {"P_int", "P_thr", "start_offset",
         # "service_food", "service_waste", ...} arms the engine's generator; it draws day 0 from the global stream now
         self._service_cfg = dict(traffic or {})
+        self._traffic_armed = traffic is not None
         if traffic is not None:
             engine.set_traffic_generator(tables, internal_per_day=traffic.get("P_int", 10000),
                                          passing_per_day=traffic.get("P_thr", 2400),
