@@ -97,10 +97,14 @@ def run_facade_with_generator(engine, name="service_64_s15", ticks=420):
                 assert v.get_portrayal()["Type"].endswith("ServiceVehicle")
         got = np.asarray([[b.get_food_units(), b.get_waste_units()] for b in m.city_blocks.values()])
         assert np.array_equal(got, tr["blk_rows"][t])
-    stats = m.dynamic_traffic_generator.cached_stats
+    # the generator's live attributes (dynamic_traffic_generator.py:102-131) follow the tick; its cached_stats is the dict the
+    # generator refreshed at its last update (every STATISTICS_UPDATE_INTERVAL ticks), as in the reference
+    dta = m.dynamic_traffic_generator
     want_c = dict(zip(fields, tr["cnt_rows"][ticks - 1]))
     for k in ("created_service_food", "created_service_waste", "live_service_food", "live_service_waste", "live_through", "parked"):
-        assert stats[k] == want_c[k], k
+        assert getattr(dta, k) == want_c[k], k
+    stats = dta.cached_stats
+    assert (stats == {}) == (ticks < 20) and (ticks < 20 or "daily_total_service_food" in stats)
     assert seen_service, "the scenario is expected to spawn service vehicles"
     # a vehicle added through the facade after engine-side spawns gets the next free spawn index
     v = VehicleAgent("late_one", m, m.cell(*map(int, tr["v_start_xy"][0])), m.cell(*map(int, tr["v_goal_xy"][0])))
