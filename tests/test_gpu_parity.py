@@ -391,7 +391,7 @@ def test_hip_vs_oracle_long_run_word_ring_wraps():
 
 @pytest.mark.parametrize("name", ["full_96_s8", "default_200_s20", "faults_64_s9", "startgoal_96_s27"])
 def test_hip_quad_searcher_reproduces_reference_trace(monkeypatch, name):
-    """k_replan_quad (astar_quad.h: sixteen searches per wave; by default only for queues of 65 536 entries and more) with k_replan beside it on the hand-backs,
+    """k_replan_quad (astar_quad.h: sixteen searches per wave; by default only for queues of 262 144 entries and more) with k_replan beside it on the hand-backs,
     forced on for every tick of a captured run: the same per-tick comparison against the reference's recorded state."""
     from trafficsimulation_amd._lib import new_engine
     monkeypatch.setenv("TS_QUAD", "1")

@@ -1227,6 +1227,13 @@ __device__ __attribute__((noinline)) int replan_turn(const Dev& d, const TsParam
   // (sharded mode: the queue is in the same total order on every rank - run_replans sorts it by (key, index) - and entry j
   // of it is rank j % world's; hand-backs of this rank's own quads are this rank's)
   if (q.world > 1 && j < n3 + n2 + n1 + n0 && (j % q.world) != q.rank) return 1;
+  // the most expensive classes are a tick's critical path (its longest search bounds it): their waves take the issue slots
+  // of their SIMD first, the five waves beside them fill in behind (`s_setprio`; TS_NO_PRIO: a build without it)
+#ifndef TS_NO_PRIO
+  if (j < n3) __builtin_amdgcn_s_setprio(3);
+  else if (j < n3 + n2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
   const long long c0 = S->calls, e0 = S->expansions, r0 = S->relaxations;
   const int r = uni(decide_vehicle<DM_WAVE>(d, P, i, S));
   if (threadIdx.x == 0) {

@@ -116,7 +116,7 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   // searches per wave, on its own stream) while k_replan runs beside it on the most expensive class and on every vehicle
   // the quads hand back as they work (searches that outgrow their window, heap or expansion budget, step-limited ones).
   // Smaller queues are bounded by their longest search, and that one is faster alone on a wave.
-  const int quad_min = getenv("TS_QUAD_MIN") ? atoi(getenv("TS_QUAD_MIN")) : 65536;
+  const int quad_min = getenv("TS_QUAD_MIN") ? atoi(getenv("TS_QUAD_MIN")) : 262144;
   bool split_done = false;      // (the queue is split between the ranks once; what is queued again - pool-full entries, hand-backs - is this rank's own)
   // (not in the sharded multi-GPU mode: its ranks split one queue between k_replan launches)
   if (e->quad_on && e->dist_world == 1 && replan_pending(e->hint + 8) >= std::max(quad_min, 1)) { rc = ensure_qslots(e); if (rc) return rc; }
