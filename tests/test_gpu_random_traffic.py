@@ -56,7 +56,7 @@ def run_case(case, make_engines, ticks):
     for e in apis:
         build_engine(e, tables, defaults=d, global_seed=seed, sched_seed=seed + 3)
         e.set_traffic_generator(tables, internal_per_day=pops[0], passing_per_day=pops[1], start_offset_seconds=start_offset,
-                                service=svc)
+                                service=svc, statistics_update_interval=3 + case % 9)     # (cached_stats refreshed every few ticks)
         if n0:
             e.add_vehicles(tr["v_start_xy"][:n0], tr["v_goal_xy"][:n0], np.full(min(n0, len(tr["v_start_xy"])), capi.POP["through"], np.int32))
     a, b = apis
@@ -107,6 +107,10 @@ def run_case(case, make_engines, ticks):
         assert a.rng_fingerprint(capi.RNG_GLOBAL) == b.rng_fingerprint(capi.RNG_GLOBAL), f"{ctx}: global RNG"
         assert a.rng_fingerprint(capi.RNG_SCHEDULER) == b.rng_fingerprint(capi.RNG_SCHEDULER), f"{ctx}: scheduler RNG"
         assert a.num_scheduled() == b.num_scheduled(), f"{ctx}: schedule size"
+        # DynamicTrafficAgent.cached_stats: the device reduction at the generator's place in the shuffled order (service
+        # vehicles, rain clouds and day rollovers in the schedule) against the oracle's loop, every key
+        sa, sb = a.cached_stats(), b.cached_stats()
+        assert sa.keys() == sb.keys() and all(sa[k] == sb[k] for k in sa), f"{ctx}: cached_stats " + str({k: (sa[k], sb.get(k)) for k in sa if sa[k] != sb.get(k)})
         ca, cb = a.counters(), b.counters()
         for f in ("parked", "live_internal", "live_through", "count_completed_internal", "count_completed_through",
                   "total_distance_through", "created_internal", "created_through", "created_service_food",
