@@ -47,8 +47,9 @@ d.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,device_direct,tight_pool", [(2, False, False), (2, True, False), (2, True, True), (4, True, False), (5, True, False)])
-def test_ranks_sharded_replans_match_the_reference(world, device_direct, tight_pool):
+@pytest.mark.parametrize("world,device_direct,tight_pool,quads", [(2, False, False, False), (2, True, False, False), (2, True, True, False), (4, True, False, False),
+                                                               (5, True, False, False), (2, True, False, True), (4, True, False, True)])
+def test_ranks_sharded_replans_match_the_reference(world, device_direct, tight_pool, quads):
     """2, 4 and 5 ranks (with the test runner itself that is the six processes this box lets share its GPU), with the records exchanged between device buffers
     (ts_set_replan_sharding_device; the collective itself is gloo here) and once with the host-staged form."""
     # closed populations, then the agents that step on the host inside the shuffled order (traffic generator spawning and
@@ -56,8 +57,10 @@ def test_ranks_sharded_replans_match_the_reference(world, device_direct, tight_p
     traces = ["full_64_s1", "full_96_s8", "faults_64_s9", "carve_96_s10", "dta_64_s12", "rain_96_s14", "config1_64_s11", "despawn_96_s25", "startgoal_96_s27"]
     if world > 2:
         traces = ["full_96_s8", "faults_64_s9", "dta_64_s12", "config1_64_s11", "startgoal_96_s27"]
-    port = str(29541 + world + (10 if device_direct else 0) + (20 if tight_pool else 0))
+    port = str(29541 + world + (10 if device_direct else 0) + (20 if tight_pool else 0) + (40 if quads else 0))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if quads:           # (every rank's share of every queue on k_replan_quad, its hand-backs on k_replan beside it)
+        env["TS_QUAD"], env["TS_QUAD_MIN"] = "1", "1"
     if tight_pool:      # (almost no room reserved in the path pool: planners find it full, the pool is garbage-collected / grown INSIDE the
         env["TS_DEBUG_POOL_PER_ENTRY"] = "2"      # sharded tick, and the export must not rely on the pool's growth to size its buffer)
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
