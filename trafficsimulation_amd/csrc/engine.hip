@@ -118,9 +118,10 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   // Smaller queues are bounded by their longest search, and that one is faster alone on a wave.
   const int quad_min = getenv("TS_QUAD_MIN") ? atoi(getenv("TS_QUAD_MIN")) : 262144;
   bool split_done = false;      // (the queue is split between the ranks once; what is queued again - pool-full entries, hand-backs - is this rank's own)
-  // (in the sharded multi-GPU mode the threshold applies to the whole queue, of which this rank takes every world-th entry)
-  if (e->quad_on && replan_pending(e->hint + 8) >= std::max(quad_min, 1)) { rc = ensure_qslots(e); if (rc) return rc; }
-  if (e->quad_on && e->qslots_ready && replan_pending(e->hint + 8) >= std::max(quad_min, 1)) {
+  // (in the sharded multi-GPU mode the threshold applies to this rank's share: every world-th entry of the queue)
+  const bool quad_queue = replan_pending(e->hint + 8) / std::max(e->dist_world, 1) >= std::max(quad_min, 1);
+  if (e->quad_on && quad_queue) { rc = ensure_qslots(e); if (rc) return rc; }
+  if (e->quad_on && e->qslots_ready && quad_queue) {
     const int quad_mask = getenv("TS_QUAD_CLASSES") ? atoi(getenv("TS_QUAD_CLASSES")) & 15 : 7;
     int nq = 0, nw = 0;
     for (int c = 0; c < 4; c++) { if ((quad_mask >> c) & 1) nq += e->hint[8 + c]; else nw += e->hint[8 + c]; }
