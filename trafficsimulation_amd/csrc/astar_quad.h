@@ -43,7 +43,7 @@ namespace {
 constexpr int QL = TS_QUAD_LCAP;            // heap slots per search in LDS (and the stride between two searches' heaps)
 // (bank spread: the 8-byte slots of the eight quads of a half-wave at the same heap index must fall into different banks)
 static_assert(QL % 8 == 4, "TS_QUAD_LCAP must be 4 mod 8 (LDS bank spread between the quads of a wave)");
-static_assert((size_t)16 * QL * 8 * TS_QUAD_WAVES_PER_CU <= 160 * 1024 - 512, "the LDS heaps of TS_QUAD_WAVES_PER_CU waves must fit a CU");
+static_assert(((size_t)16 * QL + 64) * 8 * TS_QUAD_WAVES_PER_CU <= 160 * 1024 - 512, "the LDS heaps of TS_QUAD_WAVES_PER_CU waves must fit a CU");
 #ifndef TS_QUAD_WINDOW
 #define TS_QUAD_WINDOW 1152
 #endif
@@ -71,8 +71,9 @@ struct QSlots {
   uint32_t* slot_epoch;
 };
 constexpr int Q_DWORDS = (QL + Q_SPILL) / 16 + 4;
+constexpr int Q_HEAP_MAX = (QL + Q_SPILL) < (32 * QL - 2) ? (QL + Q_SPILL) : (32 * QL - 2);   // largest heap a quad carries
 
-__shared__ unsigned long long q_lds[16 * QL];
+__shared__ unsigned long long q_lds[16 * QL + 64];     // (the last 64 entries: one scratch slot per lane, see q_lput_if)
 
 // quad_perm DPP: lane j of every quad reads lane P[j] of its quad
 template <int CTRL> __device__ __forceinline__ int qperm(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
@@ -136,6 +137,16 @@ __device__ __forceinline__ uint32_t q_aix(const QConst& K, int x, int y) {
 // are touched in blocks of their own, which only run for quads whose heap has outgrown LDS.
 __device__ __forceinline__ u64 q_lget(const QConst& K, int k) { return q_lds[K.lbase + k]; }
 __device__ __forceinline__ void q_lput(const QConst& K, int k, u64 v) { q_lds[K.lbase + k] = v; }
+// A store some lanes make and others do not, without a branch: the others write their own scratch slot behind the heaps.  (A
+// predicated store costs the wave an exec-mask bracket and a branch - three scalar instructions and a pipeline bubble; the
+// turn has a dozen of them, and at one or two waves per SIMD nothing hides them.)
+__device__ __forceinline__ void q_lput_if(const QConst& K, bool on, int k, u64 v) { q_lds[on ? K.lbase + k : 16 * QL + (int)threadIdx.x] = v; }
+// heap slot k for the lanes that want it (on) and whose slot lies in LDS; the store of a slot beyond LDS stays behind a branch
+// (one, and only quads whose heap has outgrown LDS take it)
+__device__ __forceinline__ void q_hput_if(const QConst& K, bool on, int k, u64 v) {
+  q_lput_if(K, on & (k < QL), k, v);
+  if (on & (k >= QL)) K.gq[k - QL] = v;
+}
 // A load from the HBM spill in one of the turn's rare side paths, waited for on the spot and kept out of the compiler's
 // bookkeeping of outstanding memory operations: a load it can see behind a branch costs an unconditional
 // `s_waitcnt vmcnt(0)` where the branch rejoins - for every quad of the wave, on every turn, and with the turn's stores
@@ -167,8 +178,13 @@ __device__ __forceinline__ QPair quad_sift2_load(const QConst& K, int p, int siz
   QPair r;
   r.cv = c < size; r.gv = gc < size;
   r.ce = 0; r.ge = 0;
-  if (r.cv) r.ce = DEEP ? q_hget(K, c) : q_lget(K, c);
-  if (r.gv) r.ge = DEEP ? q_hget(K, gc) : q_lget(K, gc);
+  if (DEEP) {
+    if (r.cv) r.ce = q_hget(K, c);
+    if (r.gv) r.ge = q_hget(K, gc);
+  } else {       // (no branch around the reads: a slot that does not exist is read at the root and not used)
+    r.ce = q_lget(K, r.cv ? c : 0);
+    r.ge = q_lget(K, r.gv ? gc : 0);
+  }
   return r;
 }
 // The same fetch with nothing conditional about it: an LDS read and an HBM load per entry, both always issued (clamped to
@@ -198,13 +214,18 @@ __device__ __forceinline__ bool quad_sift2_apply(const QConst& K, int& p, int xf
   wr0 = -1; wr1 = -1;
   if (w1 == 0) return true;
   const int sdn = w1 >> 1;                              // the hole moves to the left (0) / right (1) child
-  if (cw & (j < 2)) { if (DEEP) q_hput(K, p, r.ce); else q_lput(K, p, r.ce); }
-  wr0 = p;
   const int pc = 2 * p + 1 + sdn;
   const int w2 = (bits >> (4 + 2 * sdn)) & 3;
+  const int t = 2 * sdn + (w2 >> 1);                    // ... and on to grandchild t (if w2)
+  if (DEEP) {
+    q_hput_if(K, cw & (j < 2), p, r.ce);
+    q_hput_if(K, (w2 != 0) & (j == t), pc, r.ge);
+  } else {
+    q_lput_if(K, cw & (j < 2), p, r.ce);
+    q_lput_if(K, (w2 != 0) & (j == t), pc, r.ge);
+  }
+  wr0 = p;
   if (w2 == 0) { p = pc; return true; }
-  const int t = 2 * sdn + (w2 >> 1);                    // ... and on to grandchild t
-  if (j == t) { if (DEEP) q_hput(K, pc, r.ge); else q_lput(K, pc, r.ge); }
   wr1 = pc;
   p = 4 * p + 3 + t;
   return false;
@@ -330,7 +351,7 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
         if ((w1 >= 0) & ((w1 == pa0) | (w1 == pa1))) { if (w1 == pa0) pa0 = -1; if (w1 == pa1) pa1 = -1; }
       }
     }
-    if (j == 0) q_hput(K, p, x);
+    q_hput_if(K, j == 0, p, x);
     if (p == pa0) pa0 = -1;
     if (p == pa1) pa1 = -1;
   }
@@ -345,7 +366,8 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
     if (relax & 16) { st = QS_ABANDON; s.why = 1; break; }
     if (relax == 0) break;
     const int n_new = __builtin_popcount((unsigned)relax);
-    if (s.hs + n_new > QL + Q_SPILL) { st = QS_ABANDON; s.why = 2; break; }
+    // (a heap the spill holds and whose slots' ancestors 5 and up all lie in LDS: (i + 1) / 32 - 1 < QL)
+    if (s.hs + n_new > Q_HEAP_MAX) { st = QS_ABANDON; s.why = 2; break; }
     s.n_relax += n_new;
     if (ok) K.tab[t_ix] = (uint32_t)ngi | ((uint32_t)j << Q_DIR_SHIFT) | s.stamp;   // dist / came_from (226-227)
     const int nf0 = qperm<QP_B0>(nf_l), nf1 = qperm<QP_B1>(nf_l), nf2 = qperm<QP_B2>(nf_l), nf3 = qperm<QP_B3>(nf_l);
@@ -376,21 +398,22 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
         const int k = base + 1 + j;
         const bool has = k <= depth;
         const int a = (int)(((unsigned)(i + 1) >> (k & 31)) - 1u);
-        u64 anc = 0;
+        // (the read is unconditional - of the root for a lane without an ancestor, or whose ancestor lies beyond LDS; only the
+        // parent generation of a slot beyond 2 QL can, and its entry was requested at the pop or is fetched behind one branch)
+        u64 anc = q_lget(K, (has & (a < QL)) ? a : 0);
         if (base == 0 && i > 2 * QL) {
-          if (has) { if (a == pa) anc = pv; else anc = q_hget(K, a); }
+          if (has & (a >= QL)) { if (a == pa) anc = pv; else anc = q_gload_now(K.gq + (a - QL)); }
         }
-        else if (has) anc = q_lget(K, a);
         const bool up = has & (nf < hq_f(anc));
         const int um = quad_or(up ? (1 << j) : 0);
         const int cnt = __builtin_ctz(~(unsigned)um);      // the entry passes a PREFIX of its ancestors (heap order)
         const int dst = (int)(((unsigned)(i + 1) >> ((k - 1) & 31)) - 1u);
-        if (up) q_hput(K, dst, anc);                       // ancestor k moves to where k - 1 was
+        q_hput_if(K, up, dst, anc);                        // ancestor k moves to where k - 1 was
         rise += cnt;
         if (cnt < 4) break;
       }
       const int fin = (int)(((unsigned)(i + 1) >> (rise & 31)) - 1u);
-      if (j == 0) q_hput(K, fin, hq_pack(nf, nxy));
+      q_hput_if(K, j == 0, fin, hq_pack(nf, nxy));
       // (the copy of the next push's parent is stale once this push has risen past it: the only slot of pa1's level it writes)
       if (rise >= 1 && pa1 == ((i - 1) >> 1)) pa1 = -1;
       s.hs = i + 1;
