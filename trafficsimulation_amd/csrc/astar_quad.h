@@ -1,16 +1,17 @@
 // astar_quad.h - the replanning searches, sixteen to a wavefront (k_replan_quad).
 //
-// k_replan (astar.h) spreads ONE search over the 64 lanes of a wave: ~160 vector + ~150 scalar instructions per expansion,
-// issued for one expansion's worth of work (profiles/r02_sq_replan_2048.json).  Here a search owns a QUAD of four lanes -
+// k_replan (astar.h) spreads ONE search over the 64 lanes of a wave: 138 vector + 151 scalar instructions per expansion,
+// issued for one expansion's worth of work (profiles/r03_sq_replan_4096.json).  Here a search owns a QUAD of four lanes -
 // lane j of the quad is direction j of astar_numba.py's neighbour loop (N, E, S, W) - and the sixteen quads of a wave run
 // sixteen independent searches through one branch-light loop in lockstep: every instruction issued serves sixteen
 // expansions, nothing is wave-uniform (no scalar unit work beyond loop control), and the cross-lane traffic is quad_perm
 // DPP, which is free.  The algorithm is astar_core's, slot for slot and compare for compare:
 //   * heap: the reference's binary heap as 8-byte (f, cell) entries, the first TS_QUAD_LCAP slots of every search in LDS
-//     (16 x 316 x 8 B = 39.5 KB per wave, four waves per CU), deeper slots in the search's HBM spill.  Sift-down: lanes
-//     0 / 1 of the quad fetch the hole's two children, one DPP swap shows each its sibling's key, "my entry moves up" is
-//     one compare (strict '<', ties to the parent, then to the left child: astar_numba.py:67-85).  Sift-up: the four lanes
-//     fetch four ancestors of the new slot at once (52-65);
+//     (16 x 156 x 8 B = 19.5 KB per wave: seven waves per CU beside k_replan's side waves), deeper slots in the search's
+//     HBM spill.  Sift-down, two levels per LDS round trip: lanes 0 / 1 of the quad fetch the hole's two children, the four
+//     lanes its four grandchildren, one DPP swap shows each its sibling's key, "my entry moves up" is one compare (strict
+//     '<', ties to the parent, then to the left child: astar_numba.py:67-85).  Sift-up: the four lanes fetch four
+//     ancestors of the new slot at once (52-65);
 //   * dir_arr (indexed by heap SLOT, never moved by the sifts: the stale-slot quirk) is only ever read at the heap's
 //     last slot and written at the slots behind it - a stack.  Two bits per slot, the 32 slots around the heap's end in
 //     a register pair, the rest in HBM; slot 0 in a register of its own;
@@ -29,6 +30,10 @@
 // call stack while fifteen other quads advance theirs.  It is re-run from the top after every search instead: finished
 // searches are taken from a log (length + counters; their paths already sit in the buffers the policy handed out), the
 // first unfinished one suspends the pass (DV_SUSPEND) and becomes the quad's search.
+// Measured: 86 instructions per expansion against k_replan's 289, but only ~50 heaps of this workload
+// fit the LDS of a CU whatever the kernel, so the quads run at one to two waves per SIMD with half of each heap in HBM: worth
+// 25-30 % on a replanning wave, and slower than k_replan on a queue that is bounded by its longest search - run_replans
+// (engine.hip) sends them queues of TS_QUAD_MIN = 262 144 entries and more.
 #pragma once
 #include "astar.h"
 
