@@ -437,3 +437,14 @@ def test_hip_cached_stats_match_the_reference(hip, name):
     tr = load_trace(trace_path(name))
     setup_from_trace(hip, tr, explicit_paths=False)
     assert replay_and_compare_cached_stats(hip, tr, name) >= 9
+
+
+def test_hip_quad_searcher_with_a_full_path_pool(monkeypatch):
+    """The quads' commit finds the path pool full (TS_DEBUG_POOL_PER_ENTRY=2): their vehicles go to the retry list like k_replan's,
+    the host makes room and k_replan runs them again - state for state against the oracle."""
+    monkeypatch.setenv("TS_QUAD", "1")
+    monkeypatch.setenv("TS_QUAD_MIN", "1")
+    monkeypatch.setenv("TS_DEBUG_POOL_PER_ENTRY", "2")
+    h, c = _pair_full(512, 12_000, 9)
+    ch = _compare_full(h, c, 8)
+    assert ch.astar_calls > 5_000
