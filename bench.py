@@ -251,11 +251,12 @@ def main():
     c0 = api.counters()
     barrier()
     t0 = time.perf_counter()
-    tick_s = []
+    tick_s, tick_c = [], [c0]
     for _ in range(args.steps):   # ts_step returns only after the engine's stream has drained: one call per tick, to see the spread
         ts = time.perf_counter()
         api.step(1)
         tick_s.append(time.perf_counter() - ts)
+        tick_c.append(api.counters())     # (a 300-byte read of the counter block: inside the timed region, it only adds to it)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -370,6 +371,9 @@ def main():
                 # (this rank's ticks: under the default policy every sixth one is a replanning wave, the others are bounded
                 # by their longest search)
                 "tick_ms": {"min": min(tick_s) * 1e3, "median": sorted(tick_s)[len(tick_s) // 2] * 1e3, "max": max(tick_s) * 1e3},
+                # per timed tick: [ms, searches, expansions] - which ticks are replanning waves, and what a search-bound tick carries
+                "ticks": [[round(t * 1e3, 1), b.astar_calls - a.astar_calls, b.astar_expansions - a.astar_expansions]
+                          for t, a, b in zip(tick_s, tick_c[:-1], tick_c[1:])],
                 "warmup_seconds": warm_s,
             },
             "roofline": dict({

@@ -278,10 +278,11 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
   const uint32_t t_l = K.tab[t_ix];
   const uint32_t am_c = *(const TS_GLOBAL uint32_t*)((const TS_GLOBAL char*)K.amap + (uint32_t)(a_ixc << 3));
   const uint32_t t_c = K.tab[t_ixc];
-  // the pushes of this turn go to slots last_i, last_i + 1, ...: lane j will want ancestor 1 + j of each.  Of those only
-  // the parent generation can lie beyond LDS (slots below 4 QL): lanes 0 request the parents of the first two slots now
-  // (pa0 / pa1: those parent slots, -1 = not held; every lane knows them, lane 0 holds the entries)
-  int pa0 = last_i > 2 * QL ? (last_i - 1) >> 1 : -1, pa1 = last_i + 1 > 2 * QL ? last_i >> 1 : -1;
+  // the pushes of this turn go to slots last_i, last_i + 1, ...: lane j will want ancestor 1 + j of each, ((i + 1) >> (1 + j)) - 1.
+  // Those that lie beyond LDS are requested now, each lane its own two (pa0 / pa1: the slots, -1 = not held or in LDS)
+  int pa0 = (int)(((unsigned)(last_i + 1) >> (1 + j)) - 1u), pa1 = (int)(((unsigned)(last_i + 2) >> (1 + j)) - 1u);
+  pa0 = pa0 >= QL ? pa0 : -1;
+  pa1 = pa1 >= QL ? pa1 : -1;
   // (both loads always leave - of the spill's first entry when there is nothing to fetch: see quad_sift2_load_both)
   const u64 pv0 = K.gq[max(pa0 - QL, 0)], pv1 = K.gq[max(pa1 - QL, 0)];
   QP(0);
@@ -392,9 +393,8 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
         s.dwin = (s.dwin & ~(3ull << sh)) | ((u64)(unsigned)dd << sh);
       }
       // heap_sift_up (52-65): the four lanes fetch four ancestors of slot i at a time; ancestor k = ((i + 1) >> k) - 1.
-      // (only the parent generation of a slot beyond 2 QL can lie beyond LDS - ancestors 2 and up are below QL for every
-      // slot below 4 QL + 3, beyond that they are fetched like any slot; the parent of the first two pushes of a turn was
-      // requested at the pop, unless something has written to it since)
+      // (ancestors 1-4 of a slot beyond 2 QL can lie beyond LDS: those of the first two pushes of a turn were requested at
+      // the pop, unless something has written to them since; the rest are fetched like any slot)
       const int depth = 31 - __builtin_clz((unsigned)(i + 1));
       const int pa = npush == 0 ? pa0 : npush == 1 ? pa1 : -1;
       const u64 pv = npush == 0 ? pv0 : pv1;
@@ -403,8 +403,8 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
         const int k = base + 1 + j;
         const bool has = k <= depth;
         const int a = (int)(((unsigned)(i + 1) >> (k & 31)) - 1u);
-        // (the read is unconditional - of the root for a lane without an ancestor, or whose ancestor lies beyond LDS; only the
-        // parent generation of a slot beyond 2 QL can, and its entry was requested at the pop or is fetched behind one branch)
+        // (the read is unconditional - of the root for a lane without an ancestor, or whose ancestor lies beyond LDS: that
+        // entry was requested at the pop or is fetched behind one branch)
         u64 anc = q_lget(K, (has & (a < QL)) ? a : 0);
         if (base == 0 && i > 2 * QL) {
           if (has & (a >= QL)) { if (a == pa) anc = pv; else anc = q_gload_now(K.gq + (a - QL)); }
@@ -419,8 +419,12 @@ __device__ __forceinline__ int quad_turn(const QConst& K, QState& s) {
       }
       const int fin = (int)(((unsigned)(i + 1) >> (rise & 31)) - 1u);
       q_hput_if(K, j == 0, fin, hq_pack(nf, nxy));
-      // (the copy of the next push's parent is stale once this push has risen past it: the only slot of pa1's level it writes)
-      if (rise >= 1 && pa1 == ((i - 1) >> 1)) pa1 = -1;
+      // (this push wrote ancestors 0 .. rise of slot i: a lane's copy for the next push is stale if its slot is one of them -
+      // on the copy's level that can only be ancestor 1 + j, or j where slot i + 1 opens a new level)
+      {
+        const int w_a = (int)(((unsigned)(i + 1) >> (1 + j)) - 1u), w_b = (int)(((unsigned)(i + 1) >> j) - 1u);
+        if (((pa1 == w_a) & (1 + j <= rise)) | ((pa1 == w_b) & (j <= rise))) pa1 = -1;
+      }
       s.hs = i + 1;
       npush++;
       wave_mem_sync();
