@@ -1167,6 +1167,12 @@ __global__ void k_replan_keys(Dev d, const int32_t* list, int n, uint32_t* keys)
 // k_replan's loop, hipcc 7.2 threaded the lane-0-only parts (queue pop, accounting) of consecutive turns together and
 // let lane 0 run the loop on a path of its own, apart from the other 63 lanes - wrong for code whose lanes cooperate
 // through readlane / ballot.  A call boundary is a point where the wave is whole again.
+#ifdef TS_TRACE_REPLAN
+// profiling builds (profiles/replan_trace.py): per queue entry (start, end: low words of the 100 MHz clock; expansions;
+// predicted cost bits | searcher slot << 8)
+__device__ int4* g_rtrace = nullptr;
+__device__ int g_rtrace_cap = 0;
+#endif
 struct RQueue {
   int32_t* l[4]; int n[4]; int32_t *retry_list, *owned_list; int rank, world;
   // vehicles k_replan_quad (astar_quad.h) hands back while both kernels run: entries appear in fb_list (-1 = not yet
@@ -1235,7 +1241,15 @@ __device__ __attribute__((noinline)) int replan_turn(const Dev& d, const TsParam
   else __builtin_amdgcn_s_setprio(0);
 #endif
   const long long c0 = S->calls, e0 = S->expansions, r0 = S->relaxations;
+#ifdef TS_TRACE_REPLAN
+  const long long tr0 = wall_clock64();
+  const int tr_bits = replan_cost_bits(d, max(d.active[i], 0));
+#endif
   const int r = uni(decide_vehicle<DM_WAVE>(d, P, i, S));
+#ifdef TS_TRACE_REPLAN
+  if (threadIdx.x == 0 && g_rtrace && j < g_rtrace_cap && j < n3 + n2 + n1 + n0)
+    g_rtrace[j] = make_int4((int)(unsigned)tr0, (int)(unsigned)wall_clock64(), (int)(S->expansions - e0), tr_bits | ((int)blockIdx.x << 8));
+#endif
   if (threadIdx.x == 0) {
     if (r == DV_DONE) {  // work of attempts that are re-run after pool growth is not counted twice
       const int vid = d.active[i];

@@ -203,12 +203,32 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     if (grid > e->side_slots && e->quad_on) { rc = arena_to_waves(e); if (rc) return rc; }
     const int w_rank = split_done ? 0 : e->dist_rank, w_world = split_done ? 1 : e->dist_world;
     split_done = true;
+#ifdef TS_TRACE_REPLAN
+    static int4* tr_buf = nullptr;
+    const int tr_cap = 1 << 22;
+    if (!tr_buf) {
+      HIPOK(hipMalloc(&tr_buf, (size_t)tr_cap * sizeof(int4)));
+      HIPOK(hipMemcpyToSymbol(HIP_SYMBOL(g_rtrace), &tr_buf, sizeof(tr_buf)));
+      HIPOK(hipMemcpyToSymbol(HIP_SYMBOL(g_rtrace_cap), &tr_cap, sizeof(tr_cap)));
+    }
+    HIPOK(hipMemsetAsync(tr_buf, 0, (size_t)std::min(n, tr_cap) * sizeof(int4), st));
+#endif
     LAUNCH(e, PK_REPLAN, n, k_replan, dim3(grid), dim3(64), d, P, e->slots, rl, e->replan_list[4], w_rank, w_world,
            e->dist_world > 1 ? e->owned_list : nullptr, 15, (int32_t*)nullptr, 0, 0);
     const double tl = now_ms();
     HIPOK(hipMemcpyAsync(e->hint + 8, d.cnt->replan_n, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
     HIPOK(hipMemcpyAsync(e->hint + 3, &d.cnt->error, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
+#ifdef TS_TRACE_REPLAN
+    if (n >= 1000) {
+      std::vector<int4> h((size_t)std::min(n, tr_cap));
+      HIPOK(hipMemcpy(h.data(), tr_buf, h.size() * sizeof(int4), hipMemcpyDeviceToHost));
+      char name[128];
+      snprintf(name, sizeof(name), "gpurun_out/rtrace_tick%lld.bin", (long long)e->C.step_count);
+      if (FILE* f = fopen(name, "wb")) { fwrite(h.data(), sizeof(int4), h.size(), f); fclose(f); }
+      fprintf(stderr, "[rtrace] tick %lld: %d entries, %d searchers, %.2f ms\n", (long long)e->C.step_count, n, grid, now_ms() - tl);
+    }
+#endif
     if (getenv("TS_DEBUG_REPLAN")) {
       int dbg[8];
       HIPOK(hipMemcpy(dbg, d.cnt->dbg, sizeof(dbg), hipMemcpyDeviceToHost));
