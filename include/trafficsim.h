@@ -124,6 +124,10 @@ typedef struct TsParams {
   /* VEHICLE_RESPECT_AWARENESS (config.py:278, astar_numba.py:29-50): occupied / red cells only count as obstacles of a
    * search inside the field of view cast from its start cell (straight road runs, vehicle_awareness_range wide) */
   int32_t respect_awareness;                         /* VEHICLE_RESPECT_AWARENESS = False */
+  /* PATHFINDING_BATCHING (config.py:411, city_model.py:1855, vehicle_base.py:669): 1 = every active vehicle runs step_decide
+   * before the schedule is shuffled (run_parallel_decide); 0 = each vehicle runs it at the top of its own step(), in the
+   * shuffled order, on the maps and the global stream as the agents stepped before it left them */
+  int32_t pathfinding_batching;                      /* PATHFINDING_BATCHING = True */
 } TsParams;
 
 /* Static maps produced by world-gen (`_build_simple_maps`, city_model.py:2151-2199). */

@@ -861,7 +861,8 @@ void move_to(E* e, int vid, int new_pos) {
   }
 }
 
-// VehicleAgent.step with PATHFINDING_BATCHING=True (vehicle_base.py:666-685)
+// VehicleAgent.step (vehicle_base.py:666-685): with PATHFINDING_BATCHING=False step_decide runs here (669-670), on the
+// maps and the global stream as the agents stepped before this one left them
 void finish_service(E* e, int vid);
 void vehicle_step(E* e, int vid) {
   Vehicle& v = e->veh[vid];
@@ -870,6 +871,10 @@ void vehicle_step(E* e, int vid) {
     v.service_ticks -= 1;
     if (v.service_ticks <= 0) finish_service(e, vid);
     return;
+  }
+  if (!e->P.pathfinding_batching) {
+    // a vehicle that despawns inside its own step_decide has pos None for the rest of step(): nothing below applies to it
+    if (step_decide(e, vid)) return;
   }
   if (!v.early_exit) {
     // _execute_movement (733-753)
@@ -1415,12 +1420,13 @@ void tick(E* e) {
   if (e->P.eager_density) update_density_fast(e);
   // run_parallel_decide with one worker (1811-1829): list order; removing the current element while
   // the generator iterates the live list makes the iterator skip the following element.
+  // (PATHFINDING_BATCHING=False, 1855: no decide phase - every vehicle decides at the top of its own step)
   {
     size_t w = 0;
     for (size_t i = 0; i < e->active.size(); i++) if (e->active[i] >= 0) e->active[w++] = e->active[i];
     e->active.resize(w);
     bool skip_next = false;
-    for (size_t i = 0; i < e->active.size(); i++) {
+    for (size_t i = 0; e->P.pathfinding_batching && i < e->active.size(); i++) {
       int vid = e->active[i];
       if (vid < 0) continue;
       if (skip_next) { skip_next = false; continue; }
@@ -1510,6 +1516,7 @@ void tso_default_params(TsParams* p) {
   p->rain_radius_min = 50; p->rain_radius_max = 100; p->rain_occurrences_max = 3; p->rain_cooldown = 86400;
   p->rain_spawn_offset = 10; p->rain_spawn_chance = 0.1;
   p->stuck_despawn_enabled = 0; p->stuck_despawn_threshold = 3600; p->stuck_despawn_threshold_intersection = 20;
+  p->pathfinding_batching = 1;
 }
 
 int tso_create(const TsWorld* w, const TsParams* params, ts_handle* out) {

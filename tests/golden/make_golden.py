@@ -139,6 +139,9 @@ SCENARIOS = {
     "default_200_s20": dict(size=200, seed=20, vehicles=120, ticks=160, defaults={}),
     # config 1 of BASELINE.json: everything on (rain, traffic generator, service vehicles, city blocks)
     "config1_64_s11": dict(size=64, seed=11, vehicles=50, ticks=500, defaults={}),
+    # PATHFINDING_BATCHING=False (vehicle_base.py:666-685): step_decide inside step(), in the scheduler's shuffled order
+    "nobatch_full_96_s28": dict(size=96, seed=28, vehicles=250, ticks=80, defaults={**CLOSED, "PATHFINDING_BATCHING": False}),
+    "nobatch_config1_64_s29": dict(size=64, seed=29, vehicles=50, ticks=300, defaults={"PATHFINDING_BATCHING": False}),
 }
 
 

@@ -3,10 +3,10 @@ import numpy as np
 import pytest
 
 from trafficsimulation_amd.world import load_trace
-from tests.trace_util import CLOSED_TRACES, DEFAULT_TRACES, DTA_TRACES, RAIN_TRACES, RECT_TRACES, SERVICE_TRACES, VARIANT_TRACES, DESPAWN_TRACES, check_initial, replay_and_compare, setup_from_trace, trace_path
+from tests.trace_util import CLOSED_TRACES, DEFAULT_TRACES, DTA_TRACES, RAIN_TRACES, RECT_TRACES, SERVICE_TRACES, VARIANT_TRACES, DESPAWN_TRACES, NOBATCH_TRACES, check_initial, replay_and_compare, setup_from_trace, trace_path
 
 
-@pytest.mark.parametrize("name", CLOSED_TRACES + DTA_TRACES + RAIN_TRACES + SERVICE_TRACES + RECT_TRACES + DEFAULT_TRACES + VARIANT_TRACES + DESPAWN_TRACES)
+@pytest.mark.parametrize("name", CLOSED_TRACES + DTA_TRACES + RAIN_TRACES + SERVICE_TRACES + RECT_TRACES + DEFAULT_TRACES + VARIANT_TRACES + DESPAWN_TRACES + NOBATCH_TRACES)
 def test_oracle_reproduces_reference_trace(oracle, name):
     tr = load_trace(trace_path(name))
     setup_from_trace(oracle, tr)

@@ -62,6 +62,7 @@ class TsParams(C.Structure):
         ("rain_spawn_chance", C.c_double),
         ("stuck_despawn_enabled", C.c_int32), ("stuck_despawn_threshold", C.c_int32),
         ("stuck_despawn_threshold_intersection", C.c_int32), ("respect_awareness", C.c_int32),
+        ("pathfinding_batching", C.c_int32),
     ]
 
 
@@ -188,11 +189,11 @@ DEFAULTS_TO_PARAMS = {
     "VEHICLE_STUCK_DESPAWN_ENABLED": "stuck_despawn_enabled", "VEHICLE_STUCK_DESPAWN_THRESHOLD": "stuck_despawn_threshold",
     "VEHICLE_STUCK_DESPAWN_THRESHOLD_INTERSECTION": "stuck_despawn_threshold_intersection",
     "VEHICLE_RESPECT_AWARENESS": "respect_awareness",
+    "PATHFINDING_BATCHING": "pathfinding_batching",
 }
 # switches whose non-default value selects a code path this build does not carry: (unsupported value, why).
 # params_from_defaults refuses them loudly instead of running the default behaviour.
 UNSUPPORTED_DEFAULTS = {
-    "PATHFINDING_BATCHING": (False, "the non-batched step path (vehicle_base.py:666-685) is not carried"),
 }
 
 

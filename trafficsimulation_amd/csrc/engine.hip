@@ -1073,6 +1073,7 @@ void ts_default_params(TsParams* p) {
   p->rain_radius_min = 50; p->rain_radius_max = 100; p->rain_occurrences_max = 3; p->rain_cooldown = 86400;
   p->rain_spawn_offset = 10; p->rain_spawn_chance = 0.1;
   p->stuck_despawn_enabled = 0; p->stuck_despawn_threshold = 3600; p->stuck_despawn_threshold_intersection = 20;
+  p->pathfinding_batching = 1;
 }
 
 int ts_create(const TsWorld* w, const TsParams* params, ts_handle* out) {
