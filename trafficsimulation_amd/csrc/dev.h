@@ -72,6 +72,8 @@ struct Dev {
   unsigned long long w_magic;   // floor(2^40 / W) + 1: y = (cell * w_magic) >> 40 is exact for cell < 2^26, W < 2^14
   double elapsed;   // DynamicTrafficAgent.elapsed as the decide phase sees it (before the clock agent steps)
   int dec_expect;   // 1 + decide index of the one vehicle that may despawn inside this stretch of the decide phase (0 = none)
+  int seq;          // PATHFINDING_BATCHING=False: every vehicle decides alone, at its turn of the shuffled order - what is stored about
+                    // the other vehicles IS their state at that point (none of them is half-way through a decide phase)
   Cell* cell;
   // dense byte planes kept next to the records: occ and stop are written through (light groups sum lanes of
   // occupancy, the density map and the host read whole planes), rain is only ever read at a vehicle's own cell
@@ -164,6 +166,7 @@ __device__ __forceinline__ uint32_t claim_rank(uint32_t v, uint32_t prefix) {
 // "is ag stranded, as vehicle number my_idx of the decide order sees it" - earlier vehicles have already
 // run their step_decide this tick (countdown applied, events visible), later ones have not.
 __device__ __forceinline__ bool seen_stranded(const Dev& d, int ag, int my_idx) {
+  if (d.seq) return (d.flags[ag] & (VF_COLL | VF_MALF)) != 0;
   const uint8_t e = d.ev[ag];
   if (e) {  // stranded by a malfunction / sideswipe found during this tick's decide phase, at order index j
     const int j = d.ev_idx[ag];
@@ -185,6 +188,7 @@ __device__ __forceinline__ bool seen_stranded(const Dev& d, int ag, int my_idx) 
 __device__ __forceinline__ bool seen_parked(const Dev& d, int ag, int my_idx) {
   const uint16_t af = d.flags[ag];
   if (af & VF_PARKED) return true;
+  if (d.seq) return false;
   if (!(af & VF_KEEP) || my_idx == LAST_IDX || d.active_idx[ag] >= my_idx) return false;
   const int p = d.pos[ag];
   if (p != d.target[ag]) return false;

@@ -493,10 +493,17 @@ int tick(E* e) {
   const TsParams& P = e->P;
   hipStream_t st = e->stream;
   int nA = e->n_active, nS = e->n_sched;
+  // PATHFINDING_BATCHING=False (vehicle_base.py:669-670): no decide phase - every vehicle runs step_decide at the top of its own
+  // step(), in the shuffled order.  Here: the move phase below stops in front of every vehicle (a "point", like the traffic
+  // generator's), runs the decide machinery for that one vehicle on the maps and the stream as they are, and goes on.  One
+  // vehicle at a time is the reference's own speed limit for this switch; nothing about it is parallel.
+  const bool seq = !P.pathfinding_batching;
+  d.seq = seq ? 1 : 0;
+  if (seq && e->dist_world > 1) return fail(e, TS_E_UNSUPPORTED, "PATHFINDING_BATCHING=False has no sharded form (its decisions are sequential)");
   // Vehicles that stand on their target (a trip that ends where it starts) despawn inside the decide phase
   // (vehicle_base.py:657-661) - and leave the schedule before it is shuffled.  `standing` = their decide indices.
   std::vector<int32_t> standing;
-  if (e->standing_possible && nA > 0) {
+  if (e->standing_possible && nA > 0 && !seq) {
     if (!e->d_standing) HIPOK(dalloc(e, &e->d_standing, (size_t)E::STANDING_CAP + 1));
     HIPOK(hipMemsetAsync(e->d_standing, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_find_standing, dim3(nblk(nA)), dim3(BLK), 0, st, d, nA, e->d_standing, (int)E::STANDING_CAP);
@@ -537,8 +544,6 @@ int tick(E* e) {
     return TS_OK;
   };
   // ---------------- decide ----------------
-  if (nA > 0) {
-    HIPOK(hipMemsetAsync(d.ev, 0, (size_t)e->n_vehicles_total, st));
     // One stretch [lo, hi) of the decide order, start to finish: draws, step_decide, the searches it asks for.  A tick
     // is one stretch unless a vehicle may despawn inside the decide phase (see below).
     auto decide_range = [&](const int lo, const int hi) -> int {
@@ -755,6 +760,9 @@ int tick(E* e) {
     } else if (replan_pending(e->hint + 8) > 0) { int rc = run_replans(e); if (rc) return rc; }
     return TS_OK;
     };
+  if (nA > 0 && seq) HIPOK(hipMemsetAsync(d.ev, 0, (size_t)e->n_vehicles_total, st));
+  if (nA > 0 && !seq) {
+    HIPOK(hipMemsetAsync(d.ev, 0, (size_t)e->n_vehicles_total, st));
     if (!careful) {
       int rc = decide_range(0, nA);
       if (rc) return rc;
@@ -810,7 +818,7 @@ int tick(E* e) {
       if (n_rec > 0) {
         int rc = fetch_records(n_rec);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_decide_arrive, dim3(nblk(n_rec)), dim3(BLK), 0, st, d, n_rec);
+        hipLaunchKernelGGL(k_decide_arrive, dim3(nblk(n_rec)), dim3(BLK), 0, st, d, 0, n_rec);
         std::vector<std::pair<int, int>> order;   // (decide index, vehicle)
         for (int k = 0; k < n_rec; k++) if (recs[3 * k + 2] == AR_DECIDE) order.push_back({recs[3 * k], recs[3 * k + 1]});
         std::sort(order.begin(), order.end());
@@ -904,6 +912,26 @@ int tick(E* e) {
           points.push_back(Point{(uint32_t)sr[2 * (nb + q) + 1], 1, e->svc[fin[q]].vid, sr[2 * (nb + q)]});
       }
     }
+    if (seq && nA > 0) {
+      // kind 2 = a vehicle about to step: its step_decide runs first (ServiceVehicleAgent.step returns before it while servicing,
+      // vehicle_service.py:43-49).  ref = its index in the decide order.
+      std::vector<uint32_t> rk((size_t)nS);
+      std::vector<int8_t> kinds((size_t)nS);
+      std::vector<int32_t> refs((size_t)nS), aidx((size_t)e->n_vehicles_total);
+      std::vector<uint16_t> fl((size_t)e->n_vehicles_total);
+      HIPOK(hipMemcpyAsync(rk.data(), d.rank, (size_t)nS * 4, hipMemcpyDeviceToHost, st));
+      HIPOK(hipMemcpyAsync(kinds.data(), d.sched_kind, (size_t)nS, hipMemcpyDeviceToHost, st));
+      HIPOK(hipMemcpyAsync(refs.data(), d.sched_ref, (size_t)nS * 4, hipMemcpyDeviceToHost, st));
+      HIPOK(hipMemcpyAsync(aidx.data(), d.active_idx, (size_t)e->n_vehicles_total * 4, hipMemcpyDeviceToHost, st));
+      HIPOK(hipMemcpyAsync(fl.data(), d.flags, (size_t)e->n_vehicles_total * 2, hipMemcpyDeviceToHost, st));
+      HIPOK(hipStreamSynchronize(st));
+      for (int q = 0; q < nS; q++) {
+        if (kinds[q] != K_VEHICLE) continue;
+        const int vid = refs[q];
+        if (fl[vid] & VF_SERVICING) continue;
+        points.push_back(Point{rk[q], 2, aidx[vid], q});
+      }
+    }
     std::sort(static_events.begin(), static_events.end(), [](const StaticEv& a, const StaticEv& b) { return a.rank < b.rank; });
     std::sort(points.begin(), points.end(), [](const Point& a, const Point& b) { return a.rank < b.rank; });
     size_t se_cur = 0;
@@ -933,7 +961,14 @@ int tick(E* e) {
       for (const Ev& ev : evs) {
         if (ev.kind == 0) {
           const HostEv& h = host_events[ev.ref];
-          if (h.hid == 0) { int rc = rain_manager_step(e, discs); if (rc) return rc; }
+          if (h.hid == 0) {
+            int rc = rain_manager_step(e, discs); if (rc) return rc;
+            if (seq && discs.n >= 0) {   // the vehicles that decide after the manager in this tick read the new rain_map (vehicle_base.py:104)
+              hipLaunchKernelGGL(k_rain_map, dim3(nblk((long long)e->N)), dim3(BLK), 0, st, d.rain, e->W, e->H, e->prev_discs, discs);
+              e->prev_discs = discs;
+              discs.n = -1;
+            }
+          }
           else if (rain_agent_step(e, h.hid)) {
             const int8_t dead = K_DEAD;   // schedule.remove(self)
             HIPOK(hipMemcpyAsync(d.sched_kind + h.slot, &dead, 1, hipMemcpyHostToDevice, st));
@@ -996,6 +1031,34 @@ int tick(E* e) {
       }
       const int dev_error = e->hint[3], dev_deaths = e->hint[1];
       { int rc = run_window(last ? NO_RANK : rank_limit); if (rc) return rc; }
+      if (!last && points[pi].kind == 2) {
+        // step_decide of the vehicle whose turn it is (vehicle_base.py:669-670), alone: draws from the stream where it stands,
+        // searches on the maps as they are, flags / parking / despawn applied before anybody else looks
+        const int i = points[pi].ref;
+        d.elapsed = e->C.elapsed;
+        e->amap_valid = false;
+        d.dec_expect = i + 1;
+        HIPOK(hipMemsetAsync(&d.cnt->dec_arrived, 0, sizeof(int), st));
+        int rc = decide_range(i, i + 1);
+        d.dec_expect = 0;
+        if (rc) return rc;
+        int after[2] = {0, 0};
+        HIPOK(hipMemcpyAsync(&after[0], &d.cnt->dec_arrived, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPOK(hipMemcpyAsync(&after[1], &d.cnt->arr_n, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        if (after[0] == i + 1) hipLaunchKernelGGL(k_decide_despawn, dim3(1), dim3(64), 0, st, d, P, i, -1);
+        if (svc_on && after[1] > arr_read) {
+          const int first = arr_read;
+          rc = fetch_records(after[1]);
+          if (rc) return rc;
+          hipLaunchKernelGGL(k_decide_arrive, dim3(nblk(after[1] - first)), dim3(BLK), 0, st, d, first, after[1]);
+          for (size_t k = 0; k + 2 < recs.size(); k += 3)
+            if (recs[k + 2] == AR_DECIDE) { int q = svc_find(e, recs[k + 1]); if (q >= 0) svc_start(e, e->svc[q]); }
+        }
+        e->amap_valid = false;
+        e->hint[3] = dev_error; e->hint[1] = dev_deaths;
+        continue;      // (its movement belongs to the rounds in front of the next point)
+      }
       if (!last) {
         const Point& pt = points[pi];
         if (pt.kind == 0) {

@@ -37,7 +37,7 @@ __global__ void k_decide_pre(Dev d, TsParams P, int start, int n_active) {
           if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
           for (int ag = d.cell[ny * W + nx].veh; ag >= 0; ag = d.next_in_cell[ag]) {
             uint16_t af = d.flags[ag];
-            bool earlier = d.active_idx[ag] < i;
+            bool earlier = !d.seq && d.active_idx[ag] < i;
             bool ag_sb = (af & (VF_COLL | VF_MALF)) != 0;
             bool ag_str = earlier ? (d.ev[ag] ? true : ((ag_sb && d.stranded_left[ag] - 1 > 0) || !P.malfunction_active)) : ag_sb;
             bool cs_pos = earlier ? (!ag_str && d.cell[d.pos[ag]].stop != 1) : (d.cur_speed[ag] > 0);
@@ -90,7 +90,7 @@ __global__ void k_apply_event(Dev d, TsParams P, int vid, int is_collision, int 
     }
     d.flags[partner] = (d.flags[partner] | VF_COLL) & ~VF_MALF;
     d.stranded_left[partner] = P.sideswipe_duration;
-    if (d.active_idx[partner] < my_idx) {
+    if (!d.seq && d.active_idx[partner] < my_idx) {
       // already decided this tick: k_decide_main still needs its pre-collision base_speed to reproduce that
       // decision, and zeroes base/current speed itself afterwards (ev == 2)
       d.ev[partner] = 2;
@@ -839,8 +839,8 @@ __global__ void k_cells_to_plane(const Cell* cell, int n, int8_t* plane) {   // 
 
 // on_target_reached inside step_decide for the vehicles that stay (AR_DECIDE records): the flag changes other
 // deciders must not see half-way are applied once the decide kernels are done
-__global__ void k_decide_arrive(Dev d, int n_rec) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_decide_arrive(Dev d, int first, int n_rec) {
+  int k = first + blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_rec || d.arr[3 * k + 2] != AR_DECIDE) return;
   const int vid = d.arr[3 * k + 1];
   uint16_t f = d.flags[vid];
