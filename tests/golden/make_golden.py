@@ -142,6 +142,12 @@ SCENARIOS = {
     # PATHFINDING_BATCHING=False (vehicle_base.py:666-685): step_decide inside step(), in the scheduler's shuffled order
     "nobatch_full_96_s28": dict(size=96, seed=28, vehicles=250, ticks=80, defaults={**CLOSED, "PATHFINDING_BATCHING": False}),
     "nobatch_config1_64_s29": dict(size=64, seed=29, vehicles=50, ticks=300, defaults={"PATHFINDING_BATCHING": False}),
+    # ... with a busy service fleet (vehicles that start a service inside their own step_decide, i.e. inside their step())
+    "nobatch_service_96_s30": dict(size=96, seed=30, vehicles=20, ticks=400,
+                                   defaults={"RAIN_ENABLED": False, "INTERNAL_POPULATION_TRAFFIC_PER_DAY": 3000,
+                                             "PASSING_POPULATION_TRAFFIC_PER_DAY": 2000, "TOTAL_SERVICE_VEHICLES_FOOD": 3000,
+                                             "TOTAL_SERVICE_VEHICLES_WASTE": 3000, "SERVICE_VEHICLE_LOAD_TIME": 1,
+                                             "SERVICE_VEHICLE_MAX_LOAD_FOOD": 50, "PATHFINDING_BATCHING": False}),
 }
 
 

@@ -1,7 +1,7 @@
 """Randomised differential test: HIP engine vs CPU oracle on small synthetic worlds with parameter sets drawn at
 random (light algorithms, speed ranges with power-of-two and non-power-of-two spans, awareness range, replanning
 thresholds, contraflow switches, stranding chances, penalties, rain with a manager, transition timers, stuck despawn,
-field-of-view masking, fractional road-type penalties).  Every
+field-of-view masking, fractional road-type penalties, the non-batched step path).  Every
 tick is compared state for state; the draws are seeded, so a failure names its case."""
 import os
 
@@ -56,6 +56,10 @@ def random_case(case: int):
         "VEHICLE_TURN_PENALTY": int(rng.choice([10, 3])),
     }
     vehicles = int(rng.integers(40, 700))
+    # round 3: the non-batched step path for every fifth case or so (a stream of its own: the other draws of a case stay what they were)
+    if np.random.default_rng(9000 + case).integers(5) == 0:
+        d["PATHFINDING_BATCHING"] = False
+        vehicles = min(vehicles, 250)
     with_manager = d["RAIN_ENABLED"]
     return size, vehicles, d, with_manager, int(rng.integers(1, 10 ** 6))
 

@@ -31,7 +31,7 @@ VARIANT_TRACES = ["unopt_96_s21", "ring_r1_112_s22", "noring_96_s23", "fwdrange_
 # in every search); trips that end where they start (despawn inside the decide phase, the next vehicle's decide is skipped)
 DESPAWN_TRACES = ["despawn_96_s25", "fov_96_s26", "startgoal_96_s27"]
 # PATHFINDING_BATCHING=False (vehicle_base.py:666-685): step_decide inside step(), in the shuffled order
-NOBATCH_TRACES = ["nobatch_full_96_s28", "nobatch_config1_64_s29"]
+NOBATCH_TRACES = ["nobatch_full_96_s28", "nobatch_config1_64_s29", "nobatch_service_96_s30"]
 DEFAULT_TRACES = ["default_200_s20"]                   # CityModel() as the reference ships: 200 x 200, config.py untouched
 
 

@@ -15,7 +15,11 @@ constexpr uint16_t VF_EARLY = TS_F_EARLY_EXIT, VF_STUCK = TS_F_STUCK, VF_PARKED 
                    VF_KEEP = 512 /* remove_on_arrival == False */, VF_ALIVE = 1024,
                    // ServiceVehicleAgent (vehicle_service.py): phase "to_block" = SVC|TOBLOCK, "servicing" = SVC|SERVICING,
                    // "to_exit" = SVC alone
-                   VF_SVC = 2048, VF_SERVICING = 4096, VF_TOBLOCK = 8192;
+                   VF_SVC = 2048, VF_SERVICING = 4096, VF_TOBLOCK = 8192,
+                   // PATHFINDING_BATCHING=False only: _start_service ran inside this vehicle's own step_decide, i.e. inside its step():
+                   // the rest of that step() still runs (tick_stuck, the second on_target_reached: vehicle_base.py:678-685) before
+                   // the vehicle counts as "servicing" (whose step() returns at its top, vehicle_service.py:43-49)
+                   VF_SVCNEW = 16384;
 constexpr int LAST_IDX = 0x7FFFFFFF;  // "decides after everyone": planners that run outside the decide phase
 // service records the kernels hand to the host (key, vehicle, what)
 constexpr int AR_START = 0 /* _start_service in the move phase, key = rank */, AR_DECIDE = 1 /* on_target_reached inside

@@ -333,6 +333,7 @@ __device__ __forceinline__ void vehicle_step_dev(const Dev& d, const TsParams& P
       remove_vehicle_dev(d, vid, s, pos, f, key);
     }
   }
+  if (f & VF_SVCNEW) f = (f & ~VF_SVCNEW) | VF_SERVICING;   // (the step() in which _start_service ran inside step_decide is over)
   d.flags[vid] = f;
 }
 
@@ -845,7 +846,7 @@ __global__ void k_decide_arrive(Dev d, int first, int n_rec) {
   const int vid = d.arr[3 * k + 1];
   uint16_t f = d.flags[vid];
   if (!(f & VF_PARKED)) { f |= VF_PARKED; atomicAdd((unsigned long long*)&d.cnt->parked, 1ULL); }
-  if (f & VF_TOBLOCK) f = (f & ~VF_TOBLOCK) | VF_SERVICING;
+  if (f & VF_TOBLOCK) f = (f & ~VF_TOBLOCK) | (d.seq ? VF_SVCNEW : VF_SERVICING);
   d.flags[vid] = f;
 }
 // Vehicles that stand on their target at the start of a tick and are not kept on arrival (a trip that ends where it
