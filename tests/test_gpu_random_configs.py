@@ -57,7 +57,7 @@ def random_case(case: int):
     }
     vehicles = int(rng.integers(40, 700))
     # round 3: the non-batched step path for every fifth case or so (a stream of its own: the other draws of a case stay what they were)
-    if np.random.default_rng(9000 + case).integers(5) == 0:
+    if os.environ.get("TS_HUNT_NOBATCH") == "1" or np.random.default_rng(9000 + case).integers(5) == 0:
         d["PATHFINDING_BATCHING"] = False
         vehicles = min(vehicles, 250)
     with_manager = d["RAIN_ENABLED"]

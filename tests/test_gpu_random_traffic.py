@@ -36,7 +36,7 @@ def random_case(case: int):
         "TRAFFIC_LIGHT_AGENT_ALGORITHM": str(rng.choice(["QUEUE_ACTUATED", "FIXED_TIME", "NEIGHBOR_GREEN_WAVE"])),
         "VEHICLE_MAX_SPEED": int(rng.choice([3, 5, 8])),
     }
-    if np.random.default_rng(9100 + case).integers(4) == 0:     # (round 3: step_decide inside step(), one case in four)
+    if os.environ.get("TS_HUNT_NOBATCH") == "1" or np.random.default_rng(9100 + case).integers(4) == 0:     # (round 3: step_decide inside step(), one case in four)
         d["PATHFINDING_BATCHING"] = False
     if not rain:   # the fixture's schedule keeps its RainManager slot; without RAIN_ENABLED the reference has none
         kinds = np.asarray(tables["schedule_kinds0"])

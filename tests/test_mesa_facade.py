@@ -16,11 +16,13 @@ def run_facade_against_trace(engine, name="lights_qa_96_s2", ticks=30):
                               global_state=tr["global_rng_after_worldgen"], sched_state=tr["sched_rng_initial"])
     assert (m.width, m.height) == (int(tr["width"]), int(tr["height"]))
     vehicles = []
+    n_static = len(m.schedule.agents)            # light groups, the clock agent (and the CityBlocks of a world that has them)
+    assert n_static >= len(m.intersection_light_groups) + 1
     for i, (s, g) in enumerate(zip(tr["v_start_xy"], tr["v_goal_xy"])):
         v = VehicleAgent(f"gv_{i}", m, m.cell(int(s[0]), int(s[1])), m.cell(int(g[0]), int(g[1])), population_type="through")
         vehicles.append(v)
     assert len(m.active_vehicle_agents) == len(vehicles)
-    assert len(m.schedule.agents) == len(m.intersection_light_groups) + 1 + len(vehicles)
+    assert len(m.schedule.agents) == n_static + len(vehicles)
     H, W = m.height, m.width
     fields = tr["veh_fields"]
     for t in range(ticks):
@@ -68,6 +70,13 @@ def run_facade_against_trace(engine, name="lights_qa_96_s2", ticks=30):
 
 def test_facade_over_oracle(oracle):
     run_facade_against_trace(oracle)
+
+
+def test_facade_without_batching_over_oracle(oracle):
+    """`CityModel(defaults={"PATHFINDING_BATCHING": False})`: the reference's other step path through the same facade, against
+    the trace captured from the reference with that switch off."""
+    run_facade_against_trace(oracle, name="nobatch_full_96_s28", ticks=40)
+    assert oracle.default_params().pathfinding_batching == 1        # (batched is the default, as in config.py:411)
 
 
 def run_facade_with_generator(engine, name="service_64_s15", ticks=420):
