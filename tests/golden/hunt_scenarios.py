@@ -1,7 +1,8 @@
 """Differential hunt for the CPU oracle: one random scenario is run by the reference's own sources (make_golden's
 harness; importable only in the build container), captured as a trace under /tmp and replayed on the oracle tick by tick,
 then the world is rebuilt from (size, seed) alone.  Not a test; DESIGN.md §2 quotes the totals.
-usage: python tests/golden/hunt_scenarios.py CASE      (cases >= 100 also move the rarely-touched Defaults)"""
+usage: python tests/golden/hunt_scenarios.py CASE      (cases >= 100 also move the rarely-touched Defaults;
+HUNT_NOBATCH=1: every case with PATHFINDING_BATCHING=False)"""
 import sys, os, json, random, time
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE))); sys.path.insert(0, HERE)
@@ -41,6 +42,7 @@ if case >= 100:   # second batch: the rarely-moved knobs
     if pr.random() < 0.3: d["RAIN_OCCURRENCES_MAX"] = pr.choice([1, 3, 8]); d["RAIN_COOLDOWN"] = pr.choice([0, 5, 40])
     if pr.random() < 0.3: d["PATHFINDING_CACHE"] = pr.choice([True, False])
     if pr.random() < 0.3: d["TIME_PER_STEP_IN_SECONDS"] = pr.choice([2, 10, 30])
+if os.environ.get("HUNT_NOBATCH") == "1": d["PATHFINDING_BATCHING"] = False      # round 3: the same cases on the non-batched step path
 kw = {}
 if pr.random() < 0.3: kw["carve_subblock_roads"] = True; kw["subblock_chance"] = 0.8
 if pr.random() < 0.3: kw["ring_road_type"] = pr.choice(["R1", "R3", None])
