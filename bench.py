@@ -66,14 +66,15 @@ POLICY_TEXT = {
 }
 
 
-def make_workload(size, vehicles, seed, world="synthetic"):
+def make_workload(size, vehicles, seed, world="synthetic", carves=False):
     from trafficsimulation_amd import citygen
     t0 = time.time()
     if world == "reference":    # the reference's own city for (size, seed): exact but interpreted, minutes at 4096^2
         from trafficsimulation_amd import worldgen
-        tables = worldgen.generate_world(size, size, seed=seed, rain_enabled=False, enable_traffic=False)
-    else:
-        tables = citygen.generate(size, size, seed=seed)
+        tables = worldgen.generate_world(size, size, seed=seed, rain_enabled=False, enable_traffic=False,
+                                         carve_subblock_roads=bool(carves))
+    else:       # (carves: BASELINE config 5's "sub-block roads + L-shaped carves" on the look-alike, citygen._carve_subblock_roads)
+        tables = citygen.generate(size, size, seed=seed, carve_subblock_roads=bool(carves))
     t1 = time.time()
     lo, hi = (150, 400) if size >= 1024 else (30, 120)
     routes = citygen.make_routes(tables, vehicles, seed=seed + 1, min_len=lo, max_len=hi)
@@ -99,7 +100,7 @@ def cpu_leg(args):
     tick; it stops once --cpu-seconds of stepping are used up (checked between ticks; the parent ends it if one tick
     overruns)."""
     from oracle import pyoracle
-    tables, routes, _ = make_workload(args.size, args.vehicles, args.seed, args.world)
+    tables, routes, _ = make_workload(args.size, args.vehicles, args.seed, args.world, args.carves)
     cpu = pyoracle.load()
     ts = time.time()
     setup(cpu, tables, routes, args.seed, extra={"eager_density": 1}, policy=args.policy)
@@ -165,6 +166,7 @@ def main():
     ap.add_argument("--mode", choices=["sharded", "replicas"], default=None,
                     help="multi-GPU mode (N>1): sharded = one world, replans split over the ranks (default for --policy full); "
                          "replicas = independent worlds")
+    ap.add_argument("--carves", action="store_true", help="L-shaped one-lane roads inside the large blocks (BASELINE config 5's world)")
     ap.add_argument("--world", choices=["synthetic", "reference"], default="synthetic",
                     help="synthetic = citygen look-alike (fast to build); reference = worldgen, the reference's city for the seed")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -199,7 +201,7 @@ def main():
         cpu_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-only", "--cpu-out", cpu_out,
                                      "--size", str(args.size), "--vehicles", str(args.vehicles), "--seed", str(args.seed),
                                      "--policy", args.policy, "--world", args.world, "--cpu-seconds", str(args.cpu_seconds),
-                                     "--cpu-max-ticks", str(args.cpu_max_ticks)],
+                                     "--cpu-max-ticks", str(args.cpu_max_ticks)] + (["--carves"] if args.carves else []),
                                     env=dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))
 
     import torch
@@ -224,7 +226,7 @@ def main():
     from trafficsimulation_amd import dist as tdist
     from trafficsimulation_amd import _capi as capi_mod
     seed = args.seed + (1000 * rank if (world > 1 and mode == "replicas") else 0)
-    tables, routes, gen_t = make_workload(args.size, args.vehicles, seed, args.world)
+    tables, routes, gen_t = make_workload(args.size, args.vehicles, seed, args.world, args.carves)
     _rl = np.diff(np.asarray(routes[2], dtype=np.int64))      # cells per initial route (routes = starts, goals, offsets, directions)
     route_stats = ({"min": int(_rl.min()), "median": float(np.median(_rl)), "mean": float(_rl.mean()), "max": int(_rl.max()),
                     "kind": "random walks along the flow; the goal is where the walk ends"} if len(_rl) else None)
@@ -351,7 +353,7 @@ def main():
             "scaling": "strong" if (world > 1 and mode == "sharded") else "weak",
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {
-                "workload": f"{args.size}x{args.size} " + ("synthetic city (citygen" if args.world == "synthetic" else "reference-generated city (worldgen")
+                "workload": f"{args.size}x{args.size} " + ("synthetic city (citygen" if args.world == "synthetic" else "reference-generated city (worldgen") + (", sub-block carves" if args.carves else "")
                             + f" seed {args.seed}), {v0} vehicles" + (" per GPU" if mode == "replicas" and world > 1 else "")
                             + f", {POLICY_TEXT[args.policy]}; random-walk initial routes",
                 "policy": args.policy,

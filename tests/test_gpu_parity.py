@@ -42,7 +42,7 @@ def test_hip_vs_oracle_without_batching(name):
     """PATHFINDING_BATCHING=False on the worlds and populations of the other traces (frequent strandings and sideswipes,
     stuck despawns, trips that end where they start, a busy service fleet, rain, the field-of-view mask, sub-block roads,
     the traffic generator): every vehicle decides at its own turn of the shuffled order.  The oracle's form of that switch
-    is pinned by the two nobatch_* traces captured from the reference; here it is the checker, state for state, every tick."""
+    is pinned by the nobatch_* traces captured from the reference (and a hunt against it); here it is the checker, state for state, every tick."""
     from oracle import pyoracle
     from trafficsimulation_amd._lib import new_engine
     tr = dict(load_trace(trace_path(name)))
@@ -211,13 +211,13 @@ def test_hip_vs_oracle_full_policy_256():
     c.close()
 
 
-def _pair_full(size, vehicles, seed, extra=None):
+def _pair_full(size, vehicles, seed, extra=None, carves=False):
     """HIP engine and CPU oracle under the reference's default policy (bench.py --policy full: QUEUE_ACTUATED lights,
     replanning, contraflow, malfunctions / sideswipes) on the same synthetic world / routes / seeds."""
     import bench
     from oracle import pyoracle
     from trafficsimulation_amd._lib import new_engine
-    tables, routes, _ = bench.make_workload(size, vehicles, seed)
+    tables, routes, _ = bench.make_workload(size, vehicles, seed, carves=carves)
     hip_api, cpu_api = new_engine(), pyoracle.load()
     bench.setup(hip_api, tables, routes, seed, extra=extra, policy="full")
     bench.setup(cpu_api, tables, routes, seed, extra=extra, policy="full")
@@ -248,6 +248,15 @@ def _compare_full(h, c, ticks, every=1):
     h.close()
     c.close()
     return ch
+
+
+def test_hip_vs_oracle_full_policy_512_with_carved_blocks():
+    """The default policy on a synthetic world with sub-block roads / L-shaped carves (BASELINE config 5's kind of world; the
+    reference's own carved city is the trace carve_96_s10): the searches route through the one-lane roads inside the blocks,
+    through a replanning wave."""
+    h, c = _pair_full(512, 12_000, 9, carves=True)
+    ch = _compare_full(h, c, 9)
+    assert ch.astar_calls > 5_000
 
 
 def test_hip_vs_oracle_full_policy_512_through_a_replanning_wave():
@@ -309,13 +318,15 @@ def test_hip_vs_oracle_full_size_4096_1m():
 
 
 def test_hip_vs_oracle_config5_size_8192_4m():
-    """BASELINE config 5's size on ONE GPU: 8192 x 8192, 4 x 10^6 vehicles + 3.3 x 10^5 QUEUE_ACTUATED light groups (more
+    """BASELINE config 5's size and kind of world on ONE GPU: 8192 x 8192 with sub-block roads / L-shaped carves
+    (citygen's form of city_model.py:563-737), 4 x 10^6 vehicles + 3.3 x 10^5 QUEUE_ACTUATED light groups (more
     than 2^22 scheduled agents: 24-bit ranks in the claim words), replans gated off; the decide phase runs in four passes
     over the MT19937 word ring.  Three ticks, compared state for state after the last."""
     import bench
     from oracle import pyoracle
     from trafficsimulation_amd._lib import new_engine
-    tables, routes, _ = bench.make_workload(8192, 4_000_000, 1)
+    tables, routes, _ = bench.make_workload(8192, 4_000_000, 1, carves=True)      # (L-shaped one-lane roads inside the large blocks)
+    assert int(tables["carved_blocks"]) > 10_000
     h, c = new_engine(), pyoracle.load()
     bench.setup(h, tables, routes, 1, policy="lights")
     bench.setup(c, tables, routes, 1, policy="lights")

@@ -88,9 +88,55 @@ def _axis_arrays(bands, n):
     return typ, off, size, bdir, bid, ring
 
 
+def _carve_subblock_roads(seed, allowed, is_road, road_type, inter, hb, vb, chance, min_sub):
+    """L-shaped one-lane roads inside the large blocks, following `_carve_subblock_roads` (city_model.py:563-737) with
+    `subblock_roads_have_intersections=False`: a pivot at least `min_sub` cells from every side of the block's interior, one
+    arm to the western or eastern edge, one to the northern or southern, traffic flowing in along one arm and out along the
+    other; the arms run through the sidewalk up to the road beside the block, whose cell there receives the arm's arrow as
+    an extra direction (666-676).  Returns the number of blocks carved."""
+    rng = np.random.RandomState(seed)
+    opp = {N_: S_, S_: N_, E_: W_, W_: E_}
+    H, W = allowed.shape
+    carved = 0
+    for i in range(len(hb) - 1):
+        y0, y1 = hb[i][1] + 1, hb[i + 1][0] - 1                  # the gap between two bands, sidewalks included
+        if (y1 - 1) - (y0 + 1) + 1 < 2 * min_sub + 1:
+            continue
+        for j in range(len(vb) - 1):
+            x0, x1 = vb[j][1] + 1, vb[j + 1][0] - 1
+            if (x1 - 1) - (x0 + 1) + 1 < 2 * min_sub + 1 or rng.rand() > chance:
+                continue
+            px = int(rng.randint(x0 + 1 + min_sub, x1 - 1 - min_sub + 1))
+            py = int(rng.randint(y0 + 1 + min_sub, y1 - 1 - min_sub + 1))
+            hor = W_ if rng.rand() < 0.5 else E_
+            ver = S_ if rng.rand() < 0.5 else N_
+            inbound_h = rng.rand() < 0.5
+            h_arrow = opp[hor] if inbound_h else hor
+            v_arrow = ver if inbound_h else opp[ver]
+            xs = range(x0, px) if hor == W_ else range(px + 1, x1 + 1)
+            ys = range(y0, py + 1) if ver == S_ else range(py, y1 + 1)
+            for x in xs:
+                allowed[py, x] = h_arrow
+            for y in ys:
+                allowed[y, px] = v_arrow
+            allowed[py, px] = v_arrow if inbound_h else h_arrow   # the pivot: its outbound arrow only (646)
+            is_road[py, xs.start:xs.stop] = True
+            is_road[ys.start:ys.stop, px] = True
+            road_type[py, xs.start:xs.stop] = 3
+            road_type[ys.start:ys.stop, px] = 3
+            ex, ey = (x0 - 1 if hor == W_ else x1 + 1), (y0 - 1 if ver == S_ else y1 + 1)
+            if is_road[py, ex] and not inter[py, ex]:
+                allowed[py, ex] |= h_arrow
+            if is_road[ey, px] and not inter[ey, px]:
+                allowed[ey, px] |= v_arrow
+            carved += 1
+    return carved
+
+
 def generate(width: int, height: int, seed: int = 1, wall_thickness: int = 15, sidewalk_ring_width: int = 2,
              min_block_spacing: int = 6, max_block_spacing: int = 18, r1_chance: float = 0.15,
-             r2_chance: float = 0.70, min_r1_bands: int = 2, traffic_light_range: int = 10) -> dict:
+             r2_chance: float = 0.70, min_r1_bands: int = 2, traffic_light_range: int = 10,
+             carve_subblock_roads: bool = False, subblock_chance: float = 0.3, min_subblock_spacing: int = 5) -> dict:
     W, H = int(width), int(height)
     rng = np.random.RandomState(seed)
     m = wall_thickness + sidewalk_ring_width
@@ -251,6 +297,9 @@ def generate(width: int, height: int, seed: int = 1, wall_thickness: int = 15, s
         flat = np.asarray([c for r in rows for c in r], dtype=np.int32)
         return off, flat
 
+    n_carved = 0
+    if carve_subblock_roads:      # (after the light groups: their lane lists are those of the band roads)
+        n_carved = _carve_subblock_roads(seed + 7919, allowed, is_road, road_type, inter, hb, vb, subblock_chance, min_subblock_spacing)
     out = dict(width=np.int32(W), height=np.int32(H), allowed_dirs_map=allowed, is_road_map=is_road.astype(np.int8),
                road_type_map=road_type * is_road.astype(np.int8), intersection_map=inter.astype(np.int8))
     G = len(g_lights)
@@ -269,6 +318,7 @@ def generate(width: int, height: int, seed: int = 1, wall_thickness: int = 15, s
     out["g_neighbors_ctor"] = np.full((G, 4, 2), -1, np.int32)
     # schedule like the reference's constructor: groups, (no city blocks), traffic generator clock
     out["schedule_kinds0"] = np.asarray([0] * G + [3], np.int8)
+    out["carved_blocks"] = np.int32(n_carved)
     return out
 
 
