@@ -116,7 +116,10 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   // searches per wave, on its own stream) while k_replan runs beside it on the most expensive class and on every vehicle
   // the quads hand back as they work (searches that outgrow their window, heap or expansion budget, step-limited ones).
   // Smaller queues are bounded by their longest search, and that one is faster alone on a wave.
-  const int quad_min = getenv("TS_QUAD_MIN") ? atoi(getenv("TS_QUAD_MIN")) : 262144;
+  // (a queue is the quads' when it is long against what k_replan can have in flight: 262 144 entries on the 5 751 slots a 4096^2
+  // map leaves it, in proportion fewer where its node tables are bigger and its slots fewer - 1 534 at 8192^2)
+  const int quad_min = getenv("TS_QUAD_MIN") ? atoi(getenv("TS_QUAD_MIN"))
+                                             : (int)std::min<long long>(262144, std::max<long long>(16384, 46ll * e->slots.n_slots));
   bool split_done = false;      // (the queue is split between the ranks once; what is queued again - pool-full entries, hand-backs - is this rank's own)
   // (in the sharded multi-GPU mode the threshold applies to this rank's share: every world-th entry of the queue)
   const bool quad_queue = replan_pending(e->hint + 8) / std::max(e->dist_world, 1) >= std::max(quad_min, 1);
