@@ -123,7 +123,9 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
   bool split_done = false;      // (the queue is split between the ranks once; what is queued again - pool-full entries, hand-backs - is this rank's own)
   // (in the sharded multi-GPU mode the threshold applies to this rank's share: every world-th entry of the queue)
   const bool quad_queue = replan_pending(e->hint + 8) / std::max(e->dist_world, 1) >= std::max(quad_min, 1);
-  if (e->quad_on && quad_queue) { rc = ensure_qslots(e); if (rc) return rc; }
+  // (set up with the first replans of a population that will fill such a queue - its first replanning wave - rather than inside that wave)
+  const bool quad_soon = e->n_active / std::max(e->dist_world, 1) >= std::max(quad_min, 1);
+  if (e->quad_on && (quad_queue || quad_soon)) { rc = ensure_qslots(e); if (rc) return rc; }
   if (e->quad_on && e->qslots_ready && quad_queue) {
     const int quad_mask = getenv("TS_QUAD_CLASSES") ? atoi(getenv("TS_QUAD_CLASSES")) & 15 : 7;
     int nq = 0, nw = 0;
