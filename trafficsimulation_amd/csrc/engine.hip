@@ -149,7 +149,11 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     }
     // (k_replan never holds anything the quads wait for: were the two launches ever serialised, it would simply find the
     // hand-back list complete)
-    const int side_waves = getenv("TS_QUAD_SIDE_WAVES") ? atoi(getenv("TS_QUAD_SIDE_WAVES")) : 512;
+    // k_replan's waves beside the quads serve the most expensive class and the quads' hand-backs: 512 of them for a wave that hands back
+    // thousands, 384 once the previous wave handed back few (they take issue slots from the quads: measured on the bench workload's four
+    // waves, 5 678 / 2 895 / 1 379 / 2 514 hand-backs: 4.18 / 3.65 / 3.22 / 2.69 s with 512, 4.56 / 3.33 / 2.88 / 2.44 s with 384)
+    const int side_waves = getenv("TS_QUAD_SIDE_WAVES") ? atoi(getenv("TS_QUAD_SIDE_WAVES"))
+                                                        : (e->quad_last_fb < 0 || e->quad_last_fb > 4096 ? 512 : 384);
     const int wgrid = std::min(e->side_slots, std::max(std::min(nw, e->side_slots), nq > 0 ? side_waves : 1));
     if (nw > 0 || nq > 0)
       hipLaunchKernelGGL(k_replan, dim3(wgrid), dim3(64), 0, st, d, P, e->slots, rl, e->replan_list[4], e->dist_rank,
@@ -165,6 +169,7 @@ int run_replans(E* e) {   // e->hint[8..15] = replan_n as k_decide_main left it
     if (e->hint[3] == TS_E_CAPACITY) return fail(e, TS_E_CAPACITY, "an A* search exceeded its heap or path buffers");
     const int fb = qn[0], retry = e->hint[8 + 4];
     e->quad_jobs += nq; e->quad_fallbacks += fb;
+    e->quad_last_fb = fb;
 #ifdef TS_QUAD_PROF
     {
       long long pf[8];
